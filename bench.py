@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: detection Mwindows/s on synthetic 1920x1080 frames with the (synthetic, stock-profile) Haar
+frontal-face cascade, full scale pyramid (scaleFactor 1.1, minNeighbors 3) — BASELINE.json configs[1].
+
+A step = one pass of the whole detection path over a batch of frames that is already resident in HBM: pyramid, integral
+images, cascade evaluation, skip-rule filter, copy-back of the candidates, rectangle grouping, and (N > 1) the gather of
+the detections over RCCL. One process per GPU; frames shard across ranks (weak scaling: --frames per GPU per step).
+
+Prints ONE JSON line on rank 0 (see the driver contract); `roofline` prices the cascade-evaluation kernel against the
+HBM roofline with the algorithmic byte count of SURVEY.md §8d; `cpu_baseline` times the CPU oracle (a restatement of
+the reference path; OpenCV itself is not installed) on the host cores, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def make_frames(n, w, h, seed0):
+    from tests.util import frame_natural, upscale
+    tm = np.load(os.path.join(ROOT, "data", "face_template_24x24.npy"))
+    frames = np.empty((n, h, w), np.uint8)
+    for i in range(n):
+        img = frame_natural(w, h, seed0 + i)
+        rng = np.random.default_rng(10_000 + seed0 + i)
+        for k in (1.0, 1.6, 2.7, 4.5, 8.0):
+            s = int(24 * k)
+            y, x = int(rng.integers(0, h - s)), int(rng.integers(0, w - s))
+            img[y:y + s, x:x + s] = upscale(tm, s)
+        frames[i] = img
+    return frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--cascade", default=os.path.join(ROOT, "data", "haarcascade_frontalface_synthetic.xml"))
+    ap.add_argument("--scale-factor", type=float, default=1.1)
+    ap.add_argument("--min-neighbors", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--device-only", action="store_true", help="time the device pipeline only (no copy-back/grouping)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import cascadeclassifier_amd as cc
+    from cascadeclassifier_amd.distributed import gather_detections
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    dev = torch.device("cuda", local_rank)
+
+    W, H, B = args.width, args.height, args.frames
+    frames_host = make_frames(B, W, H, seed0=rank * B)
+    frames = torch.from_numpy(frames_host).to(dev)  # resident in HBM before the timed region
+    clf = cc.CascadeClassifier(args.cascade, device=local_rank, max_batch=B)
+    assert not clf.empty(), getattr(clf, "load_error", "")
+    inf = clf.info()
+    plan = cc.scale_plan(inf["win_w"], inf["win_h"], W, H, args.scale_factor)
+    windows_per_frame = int((plan["nx"].astype(np.int64) * plan["ny"]).sum())
+    integral_px = int(((plan["w"] + 1).astype(np.int64) * (plan["h"] + 1)).sum())
+    chan_bytes = 8 if inf["feature_type"] == 0 else 4
+    eval_bytes_per_frame = chan_bytes * integral_px  # every integral entry read exactly once
+
+    def step():
+        if args.device_only:
+            clf.run_device_only(frames.data_ptr(), (B, H, W), args.scale_factor)
+            return None
+        rects = clf.detect_batch(None, args.scale_factor, args.min_neighbors, device_ptr=frames.data_ptr(), shape=(B, H, W))
+        if world > 1:
+            rects = gather_detections(rects, device=dev)
+        return rects
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    clf.set_profiling(True)
+    clf.timings(reset=True)
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    sync()
+    dt = time.perf_counter() - t0
+    tm = clf.timings(reset=True)
+    clf.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_windows = windows_per_frame * B * world * args.steps
+    value = total_windows / dt / 1e6
+    eval_ms = tm["eval_ms"] / max(tm["eval_launches"], 1)  # average duration of one launch (HIP events on the detector's stream)
+    ach = eval_bytes_per_frame * B / (eval_ms * 1e-3) / 1e9 if eval_ms > 0 else 0.0
+    out = {
+        "metric": "detection Mwindows/sec (1080p, haarcascade_frontalface) + achieved HBM GB/s",
+        "value": round(value, 3),
+        "unit": "Mwindows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "i32+f32 (f64 stage sums)",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{W}x{H} Haar frontalface detection, full scale pyramid (scaleFactor {args.scale_factor}, minNeighbors "
+                        f"{args.min_neighbors}), {len(plan)} scales, {windows_per_frame} grid windows/frame",
+            "cascade": os.path.basename(args.cascade) + " (synthetic, stock 25-stage/2913-stump profile)",
+            "frames_per_gpu_per_step": B,
+            "frame_content": "1/f noise (sigma 40) + 5 pasted face templates",
+            "parallelism": f"frames sharded over {world} GPU(s); RCCL gather of detections only",
+            "timed_region": "device pipeline only" if args.device_only else
+                            "pyramid+integral+cascade eval+skip filter+candidate copy-back+host grouping" + ("+RCCL gather" if world > 1 else ""),
+        },
+        "frames_per_s": round(B * world * args.steps / dt, 2),
+        "kernel_ms_per_step": {k: round(tm[k] / args.steps, 4) for k in ("resize_ms", "integral_ms", "eval_ms", "finalize_ms")},
+        "roofline": {
+            "kernel": "k_eval_haar" if inf["feature_type"] == 0 else "k_eval_lbp",
+            "bound": "hbm",
+            "achieved": round(ach, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 5),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": eval_bytes_per_frame * B,
+            "avg_launch_ms": round(eval_ms, 4),
+        },
+    }
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        from oracle import oracle as orc
+        o = orc.load_cascade_xml(args.cascade)
+        cores = len(os.sched_getaffinity(0))
+        nfr = min(args.cpu_frames, B)
+        orc.detect_multiscale(o, frames_host[0][:270, :480], args.scale_factor, args.min_neighbors, nthreads=cores)  # warm-up
+        t0 = time.perf_counter()
+        ok = True
+        for i in range(nfr):
+            r = orc.detect_multiscale(o, frames_host[i], args.scale_factor, args.min_neighbors, nthreads=cores)
+            if last is not None:
+                ok = ok and r.shape == last[i].shape and bool((r == last[i]).all())
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": round(windows_per_frame * nfr / cdt / 1e6, 3),
+            "unit": "Mwindows/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"{nfr} of the same {W}x{H} frames, full detectMultiScale, CPU oracle (restatement of the reference path; "
+                      f"OpenCV not installed), {cores} threads over grid rows",
+            "seconds": round(cdt, 2),
+            "rectangles_identical_to_gpu": ok if last is not None else None,
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

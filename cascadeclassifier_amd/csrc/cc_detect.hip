@@ -1,0 +1,1259 @@
+// Detection hot path on gfx950: scale pyramid (bit-exact fixed-point bilinear), integral images (sum + wrap-around
+// sqsum), sliding-window cascade evaluation with early exit, stage-0 skip-rule filter. Host orchestration at the
+// bottom (cc_detector). Replaces cv::CascadeClassifier::detectMultiScale as called by the reference's detection tool
+// (tools/detection/Cpp/main.cpp:42-45); behaviour follows SURVEY.md Appendix A.
+//
+// Data layout in HBM (per frame slot f of a batch; all slabs are sized for max_batch frames):
+//   pyramid  u8   : scale s at pyr + f*pyr_frame_bytes + img_ofs[s], row pitch pitch8[s] (multiple of 4)
+//   integral i32  : sum   at integ + (f*nchan + 0)*int_frame_elems + int_ofs[s], (h+1) rows x pitchI[s] (multiple of 4)
+//                   sqsum at integ + (f*nchan + 1)*int_frame_elems + int_ofs[s]   (Haar only; u32 wrap-around)
+//   rej0 mask u64 : bit gx&63 of word mask_ofs[s] + gy*nxw[s] + (gx>>6) = window (gx,gy) was rejected AT STAGE 0
+//   candidates    : one global list {frame, scale, gx, gy} + counter; the filtered list adds the output rectangle.
+//
+// Arithmetic is compiled with -ffp-contract=off: Haar feature values and stage sums follow the CPU operation order
+// exactly (float multiply/add without fusion, double stage accumulator), which makes decisions bit-identical.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "cc_internal.h"
+
+namespace ccamd {
+
+#define CC_HIP(expr)                                                                                         \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) return set_error(CC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                           __FILE__, __LINE__);                                              \
+  } while (0)
+
+constexpr int TILE_X = 64;   // window origins per tile row = one wavefront = one rej0 mask word
+constexpr int TILE_Y = 16;   // window origin rows per tile
+constexpr int WIN_PER_THREAD = 4;  // 4 waves x 4 rows
+
+struct ScaleDev {
+  int w, h;
+  int pitch8, pitchI;
+  long long img_ofs, int_ofs, mask_ofs, win_ofs;
+  int ystep, nx, ny, nxw;
+  float scale;
+  int win_w, win_h;
+  int xtab_ofs, ytab_ofs;
+};
+
+// Haar stump in tile coordinates. ofs[j][k] = LDS offset of corner k of rect j relative to the window's tile base.
+struct HaarStumpDev {
+  int ofs[3][4];
+  float w[3];
+  float thr, left, right;
+  int nrect;
+  int pad;
+};
+struct LbpStumpDev {
+  int ofs[16];
+  float left, right;
+  int subset[8];
+  int pad[2];
+};
+
+struct CandRaw {
+  int frame, scale, gx, gy;
+};
+struct CandOut {
+  int frame, scale, gx, gy, x, y, w, h;
+};
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_segment(const int* __restrict__ first, int n, int idx) {
+  int s = 0;
+  while (s + 1 < n && first[s + 1] <= idx) s++;  // n <= a few hundred, wave-uniform
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: pyramid. One thread = 4 horizontally adjacent output pixels of one scale (one u32 store).
+// INTER_LINEAR_EXACT: horizontal 8.8 taps exact in 16 bits, vertical exact in 32 bits, (v + 2^15) >> 16.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ frames, size_t row_stride, size_t frame_stride,
+                                                int src_w, int src_h, uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+                                                const ScaleDev* __restrict__ sd, int nscales,
+                                                const int* __restrict__ blk_first, const int* __restrict__ xofs,
+                                                const uint16_t* __restrict__ xw1, const int* __restrict__ yofs,
+                                                const uint16_t* __restrict__ yw1) {
+  const int s = find_segment(blk_first, nscales, blockIdx.x);
+  const ScaleDev S = sd[s];
+  const int wpr = S.pitch8 >> 2;
+  const int word = (blockIdx.x - blk_first[s]) * 256 + threadIdx.x;
+  const int y = word / wpr, xw = word - y * wpr;
+  if (y >= S.h) return;
+  const uint8_t* src = frames + (size_t)blockIdx.y * frame_stride;
+  const int y0 = yofs[S.ytab_ofs + y];
+  const unsigned wy1 = yw1[S.ytab_ofs + y], wy0 = 256u - wy1;
+  const int y1 = min(y0 + 1, src_h - 1);
+  const uint8_t* r0 = src + (size_t)y0 * row_stride;
+  const uint8_t* r1 = src + (size_t)y1 * row_stride;
+  unsigned packed = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int x = xw * 4 + k;
+    unsigned v = 0;
+    if (x < S.w) {
+      const int x0 = xofs[S.xtab_ofs + x];
+      const unsigned wx1 = xw1[S.xtab_ofs + x], wx0 = 256u - wx1;
+      const int x1 = min(x0 + 1, src_w - 1);
+      const unsigned h0 = wx0 * r0[x0] + wx1 * r0[x1];
+      const unsigned h1 = wx0 * r1[x0] + wx1 * r1[x1];
+      v = (h0 * wy0 + h1 * wy1 + (1u << 15)) >> 16;
+    }
+    packed |= v << (8 * k);
+  }
+  uint8_t* dst = pyr + (size_t)blockIdx.y * pyr_frame_bytes + S.img_ofs + (size_t)y * S.pitch8;
+  reinterpret_cast<unsigned*>(dst)[xw] = packed;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: integral, row pass. One wavefront per output row (h+1 rows per scale; row 0 is zeros).
+// Writes the horizontal prefix sums of pixel row r-1 into integral row r (column c holds the sum of pixels < c),
+// for sum and (SQ) squared sum. 64 lanes x 4 pixels per step, wave scan by lane shuffles, carry across steps.
+// ------------------------------------------------------------------------------------------------
+template <bool SQ>
+__global__ __launch_bounds__(256) void k_integral_rows(const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+                                                       int32_t* __restrict__ integ, size_t int_frame_elems, int nchan,
+                                                       const ScaleDev* __restrict__ sd, int nscales,
+                                                       const int* __restrict__ row_first, int total_rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= total_rows) return;
+  const int s = find_segment(row_first, nscales, row);
+  const ScaleDev S = sd[s];
+  const int r = row - row_first[s];
+  int32_t* osum = integ + ((size_t)blockIdx.y * nchan + 0) * int_frame_elems + S.int_ofs + (size_t)r * S.pitchI;
+  int32_t* osq = SQ ? integ + ((size_t)blockIdx.y * nchan + 1) * int_frame_elems + S.int_ofs + (size_t)r * S.pitchI : nullptr;
+  if (r == 0) {
+    for (int c = lane * 4; c < S.pitchI; c += 256) {
+      *reinterpret_cast<int4*>(osum + c) = make_int4(0, 0, 0, 0);
+      if (SQ) *reinterpret_cast<int4*>(osq + c) = make_int4(0, 0, 0, 0);
+    }
+    return;
+  }
+  const uint8_t* src = pyr + (size_t)blockIdx.y * pyr_frame_bytes + S.img_ofs + (size_t)(r - 1) * S.pitch8;
+  unsigned carry_s = 0, carry_q = 0;
+  for (int c0 = 0; c0 < S.pitchI; c0 += 256) {
+    const int px = c0 + lane * 4;
+    unsigned word = 0;
+    if (px < S.pitch8) word = *reinterpret_cast<const unsigned*>(src + px);
+    unsigned p[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) p[k] = (px + k < S.w) ? ((word >> (8 * k)) & 0xffu) : 0u;
+    unsigned a[4], q[4];
+    a[0] = p[0];
+    q[0] = p[0] * p[0];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+      a[k] = a[k - 1] + p[k];
+      q[k] = q[k - 1] + p[k] * p[k];
+    }
+    unsigned ts = a[3], tq = q[3];  // inclusive wave scan of the per-lane totals
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned us = __shfl_up(ts, d), uq = __shfl_up(tq, d);
+      if (lane >= d) {
+        ts += us;
+        if (SQ) tq += uq;
+      }
+    }
+    const unsigned base_s = carry_s + ts - a[3], base_q = carry_q + tq - q[3];
+    const unsigned last_s = base_s + a[3], last_q = base_q + q[3];
+    unsigned prev_s = __shfl_up(last_s, 1), prev_q = __shfl_up(last_q, 1);
+    if (lane == 0) {
+      prev_s = carry_s;
+      prev_q = carry_q;
+    }
+    if (px < S.pitchI) {
+      *reinterpret_cast<int4*>(osum + px) = make_int4((int)prev_s, (int)(base_s + a[0]), (int)(base_s + a[1]), (int)(base_s + a[2]));
+      if (SQ) *reinterpret_cast<int4*>(osq + px) = make_int4((int)prev_q, (int)(base_q + q[0]), (int)(base_q + q[1]), (int)(base_q + q[2]));
+    }
+    carry_s = __shfl(last_s, 63);
+    carry_q = __shfl(last_q, 63);
+  }
+}
+
+// K3: integral, column pass (in place). One thread = 4 adjacent columns of one channel of one scale; walks down the
+// rows with a running sum. Loads are issued 8 rows ahead of the dependent adds.
+__global__ __launch_bounds__(64) void k_integral_cols(int32_t* __restrict__ integ, size_t int_frame_elems, int nchan,
+                                                      const ScaleDev* __restrict__ sd, int nscales,
+                                                      const int* __restrict__ blk_first) {
+  const int s = find_segment(blk_first, nscales, blockIdx.x);
+  const ScaleDev S = sd[s];
+  const int quad = (blockIdx.x - blk_first[s]) * 64 + threadIdx.x;
+  if (quad * 4 >= S.pitchI) return;
+  const int chan = blockIdx.z;
+  int4* p = reinterpret_cast<int4*>(integ + ((size_t)blockIdx.y * nchan + chan) * int_frame_elems + S.int_ofs) + quad;
+  const size_t pitch4 = S.pitchI >> 2;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  int r = 1;
+  for (; r + 8 <= S.h + 1; r += 8) {
+    int4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = p[(size_t)(r + k) * pitch4];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      acc.x += (unsigned)v[k].x;
+      acc.y += (unsigned)v[k].y;
+      acc.z += (unsigned)v[k].z;
+      acc.w += (unsigned)v[k].w;
+      p[(size_t)(r + k) * pitch4] = make_int4((int)acc.x, (int)acc.y, (int)acc.z, (int)acc.w);
+    }
+  }
+  for (; r <= S.h; r++) {
+    const int4 v = p[(size_t)r * pitch4];
+    acc.x += (unsigned)v.x;
+    acc.y += (unsigned)v.y;
+    acc.z += (unsigned)v.z;
+    acc.w += (unsigned)v.w;
+    p[(size_t)r * pitch4] = make_int4((int)acc.x, (int)acc.y, (int)acc.z, (int)acc.w);
+  }
+}
+
+// Tilted integral from the finished upright integral (test utility and small images only: O(h) per entry).
+// tilted(Y,X) = sum_{y<Y} rowsum_y[x0..x1], x0 = max(X-1-(Y-y-1),0), x1 = min(X-1+(Y-y-1), w-1);
+// rowsum_y[a..b] = S[y+1][b+1] - S[y][b+1] - S[y+1][a] + S[y][a].
+__global__ void k_tilted_from_sum(const int32_t* __restrict__ sum, int pitchI, int w, int h, int32_t* __restrict__ tilted,
+                                  int tpitch) {
+  const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
+  if (X > w || Y > h) return;
+  int acc = 0;
+  for (int y = 0; y < Y; y++) {
+    const int half = Y - y - 1;
+    const int x0 = max(X - 1 - half, 0), x1 = min(X - 1 + half, w - 1);
+    if (x1 >= x0) {
+      const int32_t* a = sum + (size_t)y * pitchI;
+      const int32_t* b = a + pitchI;
+      acc += b[x1 + 1] - a[x1 + 1] - b[x0] + a[x0];
+    }
+  }
+  tilted[(size_t)Y * tpitch + X] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: cascade evaluation. Block = 256 threads = 4 wavefronts = one tile of 64 x 16 window origins of one scale.
+// The tile of the `sum` integral the windows touch is staged once into LDS (for STEP 2 with even and odd columns
+// in separate planes, so that a wavefront's stride-2 corner reads are bank-conflict free); every rectangle corner
+// is then an LDS read. Lane = window column, each thread owns 4 window rows. Stage loop with early exit:
+// a wavefront leaves as soon as none of its 256 windows is alive.
+// ------------------------------------------------------------------------------------------------
+template <int STEP>
+struct TileGeom {
+  int cols, rows, plane, row_stride;
+  __host__ __device__ TileGeom(int W0, int H0) {
+    cols = (TILE_X - 1) * STEP + W0 + 1;
+    rows = (TILE_Y - 1) * STEP + H0 + 1;
+    plane = STEP == 2 ? (cols + 1) / 2 : 0;
+    row_stride = STEP == 2 ? 2 * plane : cols;
+  }
+  // LDS offset of integral entry (r, c) of the tile
+  __host__ __device__ int at(int r, int c) const {
+    return STEP == 2 ? r * row_stride + (c & 1) * plane + (c >> 1) : r * row_stride + c;
+  }
+  __host__ __device__ int words() const { return rows * row_stride; }
+};
+
+template <int STEP>
+__device__ __forceinline__ void stage_tile(int32_t* lds, const TileGeom<STEP>& G, const int32_t* __restrict__ sum,
+                                           const ScaleDev& S, int x0, int y0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < G.rows; r += 4) {
+    const int gr = y0 + r;
+    const int32_t* src = sum + (size_t)gr * S.pitchI;
+    for (int c = lane; c < G.cols; c += 64) {
+      const int gc = x0 + c;
+      int v = 0;
+      if (gr <= S.h && gc <= S.w) v = src[gc];
+      lds[G.at(r, c)] = v;
+    }
+  }
+}
+
+struct EvalArgs {
+  const int32_t* integ;
+  size_t int_frame_elems;
+  int nchan;
+  const ScaleDev* sd;
+  const int4* tiles;  // {scale, tx, ty, 0}
+  int W0, H0;
+  int nstages;
+  const int* stage_ntrees;
+  const float* stage_thr;
+  const void* stumps1;  // stump tables in STEP-1 / STEP-2 tile coordinates
+  const void* stumps2;
+  unsigned long long* masks;
+  size_t mask_frame_words;
+  CandRaw* cands;
+  int* cand_count;
+  int cand_cap;
+  int32_t* dbg_codes;  // optional, frame 0 only
+  double* dbg_sums;
+};
+
+template <int STEP>
+__device__ __forceinline__ void eval_haar_tile(const EvalArgs& A, int32_t* lds, const int4 T, const ScaleDev& S) {
+  const TileGeom<STEP> G(A.W0, A.H0);
+  const int frame = blockIdx.y;
+  const int32_t* sum = A.integ + ((size_t)frame * A.nchan + 0) * A.int_frame_elems + S.int_ofs;
+  const unsigned* sq = reinterpret_cast<const unsigned*>(A.integ + ((size_t)frame * A.nchan + 1) * A.int_frame_elems + S.int_ofs);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gx = T.y * TILE_X + lane;
+  const int x0 = T.y * TILE_X * STEP, y0 = T.z * TILE_Y * STEP;
+  stage_tile<STEP>(lds, G, sum, S, x0, y0);
+  __syncthreads();
+
+  // per-window state
+  int base[WIN_PER_THREAD];
+  float vnf[WIN_PER_THREAD];
+  bool alive[WIN_PER_THREAD];
+  int code[WIN_PER_THREAD];
+  double last[WIN_PER_THREAD];
+  const int nrx = A.W0 - 2, nry = A.H0 - 2;
+  const double area = (double)(nrx * nry);
+  const int n0 = G.at(1, 1), n1 = G.at(1, 1 + nrx), n2 = G.at(1 + nry, 1), n3 = G.at(1 + nry, 1 + nrx);
+#pragma unroll
+  for (int k = 0; k < WIN_PER_THREAD; k++) {
+    const int ly = wave * WIN_PER_THREAD + k;  // window row inside the tile
+    const int gy = T.z * TILE_Y + ly;
+    base[k] = (ly * STEP) * G.row_stride + (STEP == 2 ? lane : lane);
+    const bool in_grid = gx < S.nx && gy < S.ny;
+    alive[k] = false;
+    code[k] = -1;
+    last[k] = 0.0;
+    vnf[k] = 1.f;
+    if (in_grid) {
+      const int x = gx * STEP, y = gy * STEP;
+      const int valsum = lds[base[k] + n0] - lds[base[k] + n1] - lds[base[k] + n2] + lds[base[k] + n3];
+      const size_t q0 = (size_t)(y + 1) * S.pitchI + (x + 1);
+      const unsigned valsq = sq[q0] - sq[q0 + nrx] - sq[q0 + (size_t)nry * S.pitchI] + sq[q0 + (size_t)nry * S.pitchI + nrx];
+      double nf = area * (double)valsq - (double)valsum * (double)valsum;
+      if (nf > 0.) {
+        nf = sqrt(nf);
+        vnf[k] = (float)(1. / nf);
+        alive[k] = area * (double)vnf[k] < 1e-1;
+      }
+    }
+  }
+
+  const HaarStumpDev* __restrict__ stumps = reinterpret_cast<const HaarStumpDev*>(STEP == 2 ? A.stumps2 : A.stumps1);
+  int si = 0;
+  bool rej0[WIN_PER_THREAD] = {false, false, false, false};
+  for (int st = 0; st < A.nstages; st++) {
+    const bool any_mine = alive[0] | alive[1] | alive[2] | alive[3];
+    if (!__any(any_mine)) break;
+    const int nt = A.stage_ntrees[st];
+    double acc[WIN_PER_THREAD] = {0., 0., 0., 0.};
+    for (int i = 0; i < nt; i++, si++) {
+      const HaarStumpDev sp = stumps[si];
+      float v[WIN_PER_THREAD];
+#pragma unroll
+      for (int k = 0; k < WIN_PER_THREAD; k++) {
+        const int32_t* b = lds + base[k];
+        const int r0 = b[sp.ofs[0][0]] - b[sp.ofs[0][1]] - b[sp.ofs[0][2]] + b[sp.ofs[0][3]];
+        const int r1 = b[sp.ofs[1][0]] - b[sp.ofs[1][1]] - b[sp.ofs[1][2]] + b[sp.ofs[1][3]];
+        v[k] = sp.w[0] * (float)r0 + sp.w[1] * (float)r1;
+      }
+      if (sp.nrect == 3) {
+#pragma unroll
+        for (int k = 0; k < WIN_PER_THREAD; k++) {
+          const int32_t* b = lds + base[k];
+          const int r2 = b[sp.ofs[2][0]] - b[sp.ofs[2][1]] - b[sp.ofs[2][2]] + b[sp.ofs[2][3]];
+          v[k] += sp.w[2] * (float)r2;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < WIN_PER_THREAD; k++) {
+        const float val = v[k] * vnf[k];
+        acc[k] += (double)(val < sp.thr ? sp.left : sp.right);
+      }
+    }
+    const double thr = (double)A.stage_thr[st];
+#pragma unroll
+    for (int k = 0; k < WIN_PER_THREAD; k++) {
+      if (alive[k]) {
+        last[k] = acc[k];
+        if (acc[k] < thr) {
+          alive[k] = false;
+          code[k] = -st;
+          if (st == 0) rej0[k] = true;
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < WIN_PER_THREAD; k++) {
+    const int gy = T.z * TILE_Y + wave * WIN_PER_THREAD + k;
+    const unsigned long long m = __ballot(rej0[k]);
+    if (gy < S.ny) {
+      if (lane == 0) A.masks[(size_t)frame * A.mask_frame_words + S.mask_ofs + (size_t)gy * S.nxw + T.y] = m;
+      if (gx < S.nx) {
+        if (alive[k]) {
+          code[k] = 1;
+          const int slot = atomicAdd(A.cand_count, 1);
+          if (slot < A.cand_cap) A.cands[slot] = CandRaw{frame, T.x, gx, gy};
+        }
+        if (A.dbg_codes && frame == 0) {
+          const size_t o = (size_t)S.win_ofs + (size_t)gy * S.nx + gx;
+          A.dbg_codes[o] = code[k];
+          if (A.dbg_sums) A.dbg_sums[o] = last[k];
+        }
+      }
+    }
+  }
+}
+
+template <int STEP>
+__device__ __forceinline__ void eval_lbp_tile(const EvalArgs& A, int32_t* lds, const int4 T, const ScaleDev& S) {
+  const TileGeom<STEP> G(A.W0, A.H0);
+  const int frame = blockIdx.y;
+  const int32_t* sum = A.integ + ((size_t)frame * A.nchan + 0) * A.int_frame_elems + S.int_ofs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gx = T.y * TILE_X + lane;
+  stage_tile<STEP>(lds, G, sum, S, T.y * TILE_X * STEP, T.z * TILE_Y * STEP);
+  __syncthreads();
+
+  int base[WIN_PER_THREAD];
+  bool alive[WIN_PER_THREAD];
+  int code[WIN_PER_THREAD];
+  double last[WIN_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < WIN_PER_THREAD; k++) {
+    const int ly = wave * WIN_PER_THREAD + k;
+    base[k] = (ly * STEP) * G.row_stride + lane;
+    alive[k] = gx < S.nx && (T.z * TILE_Y + ly) < S.ny;
+    code[k] = -1;
+    last[k] = 0.0;
+  }
+  const LbpStumpDev* __restrict__ stumps = reinterpret_cast<const LbpStumpDev*>(STEP == 2 ? A.stumps2 : A.stumps1);
+  int si = 0;
+  bool rej0[WIN_PER_THREAD] = {false, false, false, false};
+  for (int st = 0; st < A.nstages; st++) {
+    const bool any_mine = alive[0] | alive[1] | alive[2] | alive[3];
+    if (!__any(any_mine)) break;
+    const int nt = A.stage_ntrees[st];
+    double acc[WIN_PER_THREAD] = {0., 0., 0., 0.};
+    for (int i = 0; i < nt; i++, si++) {
+      const LbpStumpDev* sp = stumps + si;
+#pragma unroll
+      for (int k = 0; k < WIN_PER_THREAD; k++) {
+        const int32_t* b = lds + base[k];
+        int p[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) p[j] = b[sp->ofs[j]];
+        const int c = p[5] - p[6] - p[9] + p[10];
+        const int lbp = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
+                        (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
+                        (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
+                        (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
+        const int word = reinterpret_cast<const int*>(sp->subset)[lbp >> 5];
+        acc[k] += (double)((word & (1 << (lbp & 31))) ? sp->left : sp->right);
+      }
+    }
+    const double thr = (double)A.stage_thr[st];
+#pragma unroll
+    for (int k = 0; k < WIN_PER_THREAD; k++) {
+      if (alive[k]) {
+        last[k] = acc[k];
+        if (acc[k] < thr) {
+          alive[k] = false;
+          code[k] = -st;
+          if (st == 0) rej0[k] = true;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < WIN_PER_THREAD; k++) {
+    const int gy = T.z * TILE_Y + wave * WIN_PER_THREAD + k;
+    const unsigned long long m = __ballot(rej0[k]);
+    if (gy < S.ny) {
+      if (lane == 0) A.masks[(size_t)frame * A.mask_frame_words + S.mask_ofs + (size_t)gy * S.nxw + T.y] = m;
+      if (gx < S.nx) {
+        if (alive[k]) {
+          code[k] = 1;
+          const int slot = atomicAdd(A.cand_count, 1);
+          if (slot < A.cand_cap) A.cands[slot] = CandRaw{frame, T.x, gx, gy};
+        }
+        if (A.dbg_codes && frame == 0) {
+          const size_t o = (size_t)S.win_ofs + (size_t)gy * S.nx + gx;
+          A.dbg_codes[o] = code[k];
+          if (A.dbg_sums) A.dbg_sums[o] = last[k];
+        }
+      }
+    }
+  }
+}
+
+// One launch covers every scale: the tile's scale decides (block-uniformly) which layout it uses.
+__global__ __launch_bounds__(256) void k_eval_haar(EvalArgs A) {
+  extern __shared__ int32_t lds[];
+  const int4 T = A.tiles[blockIdx.x];
+  const ScaleDev S = A.sd[T.x];
+  if (S.ystep == 2)
+    eval_haar_tile<2>(A, lds, T, S);
+  else
+    eval_haar_tile<1>(A, lds, T, S);
+}
+
+__global__ __launch_bounds__(256) void k_eval_lbp(EvalArgs A) {
+  extern __shared__ int32_t lds[];
+  const int4 T = A.tiles[blockIdx.x];
+  const ScaleDev S = A.sd[T.x];
+  if (S.ystep == 2)
+    eval_lbp_tile<2>(A, lds, T, S);
+  else
+    eval_lbp_tile<1>(A, lds, T, S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: stage-0 skip rule. OpenCV's scan loop skips the next grid position of a row after a window rejected at stage 0
+// (SURVEY.md A.5): window i is visited iff the run of consecutive stage-0 rejections immediately before it has even
+// length. Walk the rej0 bit mask backwards, a 64-bit word at a time.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool visited_by_scan(const unsigned long long* __restrict__ row_mask, int gx) {
+  int run = 0;
+  int pos = gx - 1;
+  while (pos >= 0) {
+    const int b = pos & 63;
+    const unsigned long long w = row_mask[pos >> 6] << (63 - b);  // bit `pos` now at bit 63
+    const int ones = min(__clzll((long long)~w), b + 1);          // leading ones (clz(0) = 64)
+    run += ones;
+    if (ones < b + 1) break;
+    pos -= b + 1;
+  }
+  return (run & 1) == 0;
+}
+
+__global__ __launch_bounds__(256) void k_filter_candidates(const CandRaw* __restrict__ cands, const int* __restrict__ cand_count,
+                                                           int cand_cap, const ScaleDev* __restrict__ sd,
+                                                           const unsigned long long* __restrict__ masks,
+                                                           size_t mask_frame_words, CandOut* __restrict__ out,
+                                                           int* __restrict__ out_count) {
+  const int n = min(*cand_count, cand_cap);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const CandRaw c = cands[i];
+    const ScaleDev S = sd[c.scale];
+    const unsigned long long* row = masks + (size_t)c.frame * mask_frame_words + S.mask_ofs + (size_t)c.gy * S.nxw;
+    if (!visited_by_scan(row, c.gx)) continue;
+    const int slot = atomicAdd(out_count, 1);
+    CandOut o;
+    o.frame = c.frame;
+    o.scale = c.scale;
+    o.gx = c.gx;
+    o.gy = c.gy;
+    o.x = __float2int_rn((float)(c.gx * S.ystep) * S.scale);
+    o.y = __float2int_rn((float)(c.gy * S.ystep) * S.scale);
+    o.w = S.win_w;
+    o.h = S.win_h;
+    out[slot] = o;  // out has cand_cap entries; slot < n <= cand_cap
+  }
+}
+
+__global__ void k_debug_visited(const ScaleDev* __restrict__ sd, int nscales, const int* __restrict__ rowblk_first,
+                                const unsigned long long* __restrict__ masks, uint8_t* __restrict__ visited) {
+  // one block per grid row of frame 0
+  const int s = find_segment(rowblk_first, nscales, blockIdx.x);
+  const ScaleDev S = sd[s];
+  const int gy = blockIdx.x - rowblk_first[s];
+  const unsigned long long* row = masks + S.mask_ofs + (size_t)gy * S.nxw;
+  for (int gx = threadIdx.x; gx < S.nx; gx += blockDim.x)
+    visited[(size_t)S.win_ofs + (size_t)gy * S.nx + gx] = visited_by_scan(row, gx) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t ensure(size_t count) {
+    if (count <= n) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  hipError_t upload(const std::vector<T>& v, hipStream_t st) {
+    hipError_t e = ensure(std::max<size_t>(v.size(), 1));
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st);
+  }
+};
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct Plan {
+  int w = 0, h = 0;
+  cc_detect_params p{};
+  std::vector<ScaleGeom> geom;
+  std::vector<ScaleDev> sd;
+  size_t pyr_frame_bytes = 0, int_frame_elems = 0, mask_frame_words = 0;
+  long long windows = 0, integral_elems = 0;
+  int n_resize_blocks = 0, n_rows = 0, n_col_blocks = 0, n_grid_rows = 0;
+  int n_tiles = 0;
+  DevBuf<ScaleDev> d_sd;
+  DevBuf<int> d_resize_first, d_row_first, d_col_first, d_gridrow_first, d_xofs, d_yofs;
+  DevBuf<uint16_t> d_xw1, d_yw1;
+  DevBuf<int4> d_tiles;
+};
+
+struct TimingEvent {
+  hipEvent_t a, b;
+  int kind;
+};
+
+}  // namespace ccamd
+
+using namespace ccamd;
+
+struct cc_detector {
+  Cascade m;
+  int device = 0;
+  int max_batch = 1;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  // cascade tables on the device (one per tile layout)
+  DevBuf<int> d_stage_ntrees;
+  DevBuf<float> d_stage_thr;
+  DevBuf<HaarStumpDev> d_haar1, d_haar2;
+  DevBuf<LbpStumpDev> d_lbp1, d_lbp2;
+  size_t lds = 0;  // dynamic LDS bytes per tile (larger of the two layouts)
+  // plans + workspace
+  std::vector<std::unique_ptr<Plan>> plans;
+  DevBuf<uint8_t> d_frames, d_pyr;
+  DevBuf<int32_t> d_integ;
+  DevBuf<unsigned long long> d_masks;
+  DevBuf<CandRaw> d_cands;
+  DevBuf<CandOut> d_out;
+  DevBuf<int> d_counts;  // [0] raw count, [1] filtered count
+  int cand_cap = 0;
+  DevBuf<int32_t> d_dbg_codes;
+  DevBuf<double> d_dbg_sums;
+  DevBuf<uint8_t> d_dbg_visited;
+  // profiling
+  bool profiling = false;
+  std::vector<TimingEvent> events;
+  cc_detector_timings tm{};
+
+  ~cc_detector() {
+    for (auto& e : events) {
+      (void)hipEventDestroy(e.a);
+      (void)hipEventDestroy(e.b);
+    }
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
+};
+
+namespace ccamd {
+
+static cc_status ensure_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return set_error(CC_ERR_NO_DEVICE, "no usable HIP device (%s); this library has no CPU fallback",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device < 0 || device >= n) return set_error(CC_ERR_INVALID_ARG, "device %d out of range (devices: %d)", device, n);
+  CC_HIP(hipSetDevice(device));
+  return CC_OK;
+}
+
+template <int STEP>
+static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) {
+  const TileGeom<STEP> G(m.win_w, m.win_h);
+  out.resize(m.stump_feature.size());
+  for (size_t i = 0; i < out.size(); i++) {
+    HaarStumpDev& d = out[i];
+    std::memset(&d, 0, sizeof(d));
+    const int fi = m.stump_feature[i];
+    d.nrect = 2;
+    for (int j = 0; j < 3; j++) {
+      const int32_t* r = &m.haar_rects[(size_t)fi * 12 + j * 4];
+      const float wt = m.haar_weights[(size_t)fi * 3 + j];
+      d.w[j] = wt;
+      // rects after the first zero weight contribute w*0 upstream (offsets stay 0): keep corner offsets equal
+      const bool used = j < 2 || wt != 0.0f;
+      if (j == 2 && wt != 0.0f) d.nrect = 3;
+      const int x = used ? r[0] : 0, y = used ? r[1] : 0, rw = used ? r[2] : 0, rh = used ? r[3] : 0;
+      d.ofs[j][0] = G.at(y, x);
+      d.ofs[j][1] = G.at(y, x + rw);
+      d.ofs[j][2] = G.at(y + rh, x);
+      d.ofs[j][3] = G.at(y + rh, x + rw);
+    }
+    d.thr = m.stump_threshold[i];
+    d.left = m.stump_left[i];
+    d.right = m.stump_right[i];
+  }
+}
+
+template <int STEP>
+static void build_lbp_stumps(const Cascade& m, std::vector<LbpStumpDev>& out) {
+  const TileGeom<STEP> G(m.win_w, m.win_h);
+  out.resize(m.stump_feature.size());
+  for (size_t i = 0; i < out.size(); i++) {
+    LbpStumpDev& d = out[i];
+    std::memset(&d, 0, sizeof(d));
+    const int32_t* r = &m.lbp_rects[(size_t)m.stump_feature[i] * 4];
+    for (int rr = 0; rr < 4; rr++)
+      for (int cc = 0; cc < 4; cc++) d.ofs[4 * rr + cc] = G.at(r[1] + rr * r[3], r[0] + cc * r[2]);
+    d.left = m.stump_left[i];
+    d.right = m.stump_right[i];
+    for (int j = 0; j < 8; j++) d.subset[j] = m.node_subset[i * 8 + j];
+  }
+}
+
+static bool same_params(const cc_detect_params& a, const cc_detect_params& b) {
+  return a.scale_factor == b.scale_factor && a.min_w == b.min_w && a.min_h == b.min_h && a.max_w == b.max_w && a.max_h == b.max_h;
+}
+
+static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params& p, Plan** out) {
+  for (auto& pl : d->plans)
+    if (pl->w == w && pl->h == h && same_params(pl->p, p)) {
+      *out = pl.get();
+      return CC_OK;
+    }
+  std::unique_ptr<Plan> P(new Plan());
+  P->w = w;
+  P->h = h;
+  P->p = p;
+  scale_plan(d->m.win_w, d->m.win_h, w, h, p, P->geom);
+  const int ns = (int)P->geom.size();
+  std::vector<int> resize_first(ns + 1, 0), row_first(ns + 1, 0), col_first(ns + 1, 0), gridrow_first(ns + 1, 0);
+  std::vector<int> xofs, yofs;
+  std::vector<uint16_t> xw1, yw1;
+  std::vector<int4> tiles;
+  long long img_ofs = 0, int_ofs = 0, mask_ofs = 0, win_ofs = 0;
+  P->sd.resize(ns);
+  for (int i = 0; i < ns; i++) {
+    const ScaleGeom& g = P->geom[i];
+    ScaleDev& S = P->sd[i];
+    S.w = g.w;
+    S.h = g.h;
+    S.pitch8 = align_up(g.w, 4);
+    S.pitchI = align_up(g.w + 1, 4);
+    S.img_ofs = img_ofs;
+    S.int_ofs = int_ofs;
+    S.mask_ofs = mask_ofs;
+    S.win_ofs = win_ofs;
+    S.ystep = g.ystep;
+    S.nx = g.nx;
+    S.ny = g.ny;
+    S.nxw = (g.nx + 63) / 64;
+    S.scale = g.scale;
+    S.win_w = g.win_w;
+    S.win_h = g.win_h;
+    S.xtab_ofs = (int)xofs.size();
+    S.ytab_ofs = (int)yofs.size();
+    AxisTaps tx, ty;
+    linear_exact_taps(w, g.w, tx);
+    linear_exact_taps(h, g.h, ty);
+    xofs.insert(xofs.end(), tx.ofs.begin(), tx.ofs.end());
+    xw1.insert(xw1.end(), tx.w1.begin(), tx.w1.end());
+    yofs.insert(yofs.end(), ty.ofs.begin(), ty.ofs.end());
+    yw1.insert(yw1.end(), ty.w1.begin(), ty.w1.end());
+    img_ofs += (long long)align_up(S.pitch8 * g.h, 16);
+    int_ofs += (long long)S.pitchI * (g.h + 1);
+    mask_ofs += (long long)S.nxw * g.ny;
+    win_ofs += (long long)g.nx * g.ny;
+    P->integral_elems += (long long)(g.w + 1) * (g.h + 1);
+    resize_first[i + 1] = resize_first[i] + ((S.pitch8 / 4) * g.h + 255) / 256;
+    row_first[i + 1] = row_first[i] + g.h + 1;
+    col_first[i + 1] = col_first[i] + (S.pitchI / 4 + 63) / 64;
+    gridrow_first[i + 1] = gridrow_first[i] + g.ny;
+    const int ntx = (g.nx + TILE_X - 1) / TILE_X, nty = (g.ny + TILE_Y - 1) / TILE_Y;
+    for (int ty_ = 0; ty_ < nty; ty_++)
+      for (int tx_ = 0; tx_ < ntx; tx_++) tiles.push_back(make_int4(i, tx_, ty_, 0));
+  }
+  P->pyr_frame_bytes = (size_t)((img_ofs + 15) & ~15LL);
+  P->int_frame_elems = (size_t)int_ofs;
+  P->mask_frame_words = (size_t)mask_ofs;
+  P->windows = win_ofs;
+  P->n_resize_blocks = resize_first[ns];
+  P->n_rows = row_first[ns];
+  P->n_col_blocks = col_first[ns];
+  P->n_grid_rows = gridrow_first[ns];
+  P->n_tiles = (int)tiles.size();
+  hipStream_t st = d->stream;
+  CC_HIP(P->d_sd.upload(P->sd, st));
+  CC_HIP(P->d_resize_first.upload(resize_first, st));
+  CC_HIP(P->d_row_first.upload(row_first, st));
+  CC_HIP(P->d_col_first.upload(col_first, st));
+  CC_HIP(P->d_gridrow_first.upload(gridrow_first, st));
+  CC_HIP(P->d_xofs.upload(xofs, st));
+  CC_HIP(P->d_yofs.upload(yofs, st));
+  CC_HIP(P->d_xw1.upload(xw1, st));
+  CC_HIP(P->d_yw1.upload(yw1, st));
+  CC_HIP(P->d_tiles.upload(tiles, st));
+  CC_HIP(hipStreamSynchronize(st));  // host vectors go out of scope
+  *out = P.get();
+  if (d->plans.size() >= 8) d->plans.erase(d->plans.begin());
+  d->plans.push_back(std::move(P));
+  return CC_OK;
+}
+
+enum { EV_RESIZE = 0, EV_INTEGRAL = 1, EV_EVAL = 2, EV_FILTER = 3 };
+
+struct EvScope {  // records a pair of events around a group of launches when profiling is on
+  cc_detector* d;
+  int kind;
+  hipEvent_t a = nullptr, b = nullptr;
+  EvScope(cc_detector* d_, int kind_) : d(d_), kind(kind_) {
+    if (!d->profiling) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      a = b = nullptr;
+      return;
+    }
+    (void)hipEventRecord(a, d->stream);
+  }
+  ~EvScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, d->stream);
+    d->events.push_back(TimingEvent{a, b, kind});
+  }
+};
+
+static void collect_events(cc_detector* d) {
+  for (auto& e : d->events) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      switch (e.kind) {
+        case EV_RESIZE: d->tm.resize_ms += ms; d->tm.resize_launches++; break;
+        case EV_INTEGRAL: d->tm.integral_ms += ms; d->tm.integral_launches++; break;
+        case EV_EVAL: d->tm.eval_ms += ms; d->tm.eval_launches++; break;
+        case EV_FILTER: d->tm.finalize_ms += ms; d->tm.finalize_launches++; break;
+      }
+    }
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  d->events.clear();
+}
+
+// Device pipeline for up to max_batch frames already resident on the device. Leaves the filtered candidate list
+// (d_out, d_counts[1]) on the device; no synchronisation.
+static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes, int nf, size_t row_stride,
+                                 size_t frame_stride, bool debug) {
+  const int ns = (int)P->sd.size();
+  hipStream_t st = d->stream;
+  const bool haar = d->m.feature_type == CC_FEATURE_HAAR;
+  const int nchan = haar ? 2 : 1;
+  CC_HIP(d->d_counts.ensure(2));
+  CC_HIP(hipMemsetAsync(d->d_counts.p, 0, 2 * sizeof(int), st));
+  if (ns == 0 || nf == 0) return CC_OK;
+  CC_HIP(d->d_pyr.ensure(P->pyr_frame_bytes * (size_t)d->max_batch));
+  CC_HIP(d->d_integ.ensure(P->int_frame_elems * (size_t)nchan * (size_t)d->max_batch));
+  CC_HIP(d->d_masks.ensure(std::max<size_t>(P->mask_frame_words * (size_t)d->max_batch, 1)));
+  if (d->cand_cap == 0) d->cand_cap = 1 << 18;
+  CC_HIP(d->d_cands.ensure((size_t)d->cand_cap));
+  CC_HIP(d->d_out.ensure((size_t)d->cand_cap));
+  if (debug) {
+    CC_HIP(d->d_dbg_codes.ensure((size_t)std::max<long long>(P->windows, 1)));
+    CC_HIP(d->d_dbg_sums.ensure((size_t)std::max<long long>(P->windows, 1)));
+    CC_HIP(d->d_dbg_visited.ensure((size_t)std::max<long long>(P->windows, 1)));
+  }
+  {
+    EvScope ev(d, EV_RESIZE);
+    hipLaunchKernelGGL(k_resize, dim3(P->n_resize_blocks, nf), dim3(256), 0, st, dframes, row_stride, frame_stride, P->w,
+                       P->h, d->d_pyr.p, P->pyr_frame_bytes, P->d_sd.p, ns, P->d_resize_first.p, P->d_xofs.p, P->d_xw1.p,
+                       P->d_yofs.p, P->d_yw1.p);
+  }
+  {
+    EvScope ev(d, EV_INTEGRAL);
+    const dim3 grid_rows((P->n_rows + 3) / 4, nf);
+    if (haar)
+      hipLaunchKernelGGL(k_integral_rows<true>, grid_rows, dim3(256), 0, st, d->d_pyr.p, P->pyr_frame_bytes, d->d_integ.p,
+                         P->int_frame_elems, nchan, P->d_sd.p, ns, P->d_row_first.p, P->n_rows);
+    else
+      hipLaunchKernelGGL(k_integral_rows<false>, grid_rows, dim3(256), 0, st, d->d_pyr.p, P->pyr_frame_bytes, d->d_integ.p,
+                         P->int_frame_elems, nchan, P->d_sd.p, ns, P->d_row_first.p, P->n_rows);
+    hipLaunchKernelGGL(k_integral_cols, dim3(P->n_col_blocks, nf, nchan), dim3(64), 0, st, d->d_integ.p, P->int_frame_elems,
+                       nchan, P->d_sd.p, ns, P->d_col_first.p);
+  }
+  {
+    EvScope ev(d, EV_EVAL);
+    EvalArgs A;
+    A.integ = d->d_integ.p;
+    A.int_frame_elems = P->int_frame_elems;
+    A.nchan = nchan;
+    A.sd = P->d_sd.p;
+    A.W0 = d->m.win_w;
+    A.H0 = d->m.win_h;
+    A.nstages = (int)d->m.stage_ntrees.size();
+    A.stage_ntrees = d->d_stage_ntrees.p;
+    A.stage_thr = d->d_stage_thr.p;
+    A.masks = d->d_masks.p;
+    A.mask_frame_words = P->mask_frame_words;
+    A.cands = d->d_cands.p;
+    A.cand_count = d->d_counts.p;
+    A.cand_cap = d->cand_cap;
+    A.dbg_codes = debug ? d->d_dbg_codes.p : nullptr;
+    A.dbg_sums = debug ? d->d_dbg_sums.p : nullptr;
+    A.tiles = P->d_tiles.p;
+    A.stumps1 = haar ? (const void*)d->d_haar1.p : (const void*)d->d_lbp1.p;
+    A.stumps2 = haar ? (const void*)d->d_haar2.p : (const void*)d->d_lbp2.p;
+    if (P->n_tiles) {
+      if (haar)
+        hipLaunchKernelGGL(k_eval_haar, dim3(P->n_tiles, nf), dim3(256), d->lds, st, A);
+      else
+        hipLaunchKernelGGL(k_eval_lbp, dim3(P->n_tiles, nf), dim3(256), d->lds, st, A);
+    }
+  }
+  {
+    EvScope ev(d, EV_FILTER);
+    hipLaunchKernelGGL(k_filter_candidates, dim3(64), dim3(256), 0, st, d->d_cands.p, d->d_counts.p, d->cand_cap, P->d_sd.p,
+                       d->d_masks.p, P->mask_frame_words, d->d_out.p, d->d_counts.p + 1);
+    if (debug && P->n_grid_rows)
+      hipLaunchKernelGGL(k_debug_visited, dim3(P->n_grid_rows), dim3(256), 0, st, P->d_sd.p, ns, P->d_gridrow_first.p,
+                         d->d_masks.p, d->d_dbg_visited.p);
+  }
+  CC_HIP(hipGetLastError());
+  d->tm.frames += nf;
+  d->tm.grid_windows += P->windows * nf;
+  d->tm.integral_elems += P->integral_elems * nf;
+  return CC_OK;
+}
+
+static cc_status check_frame_args(const cc_detector* d, const uint8_t* frames, int n_frames, int width, int height,
+                                  size_t row_stride, const cc_detect_params* p, const char* who) {
+  if (!d || !p || (!frames && n_frames > 0)) return set_error(CC_ERR_INVALID_ARG, "%s: null argument", who);
+  if (n_frames < 0 || width < 1 || height < 1 || row_stride < (size_t)width)
+    return set_error(CC_ERR_INVALID_ARG, "%s: bad frame geometry (%dx%d, stride %zu, n %d)", who, width, height, row_stride, n_frames);
+  if (width > 32768 || height > 32768) return set_error(CC_ERR_UNSUPPORTED, "%s: frames larger than 32768 px per side", who);
+  if (!(p->scale_factor > 1.0)) return set_error(CC_ERR_INVALID_ARG, "%s: scaleFactor must be > 1", who);
+  return CC_OK;
+}
+
+// Runs the batch in passes of max_batch frames. If collect != nullptr the filtered candidates of every pass are
+// copied back and appended (frame index made global).
+static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device, int n_frames, int width, int height,
+                           size_t row_stride, size_t frame_stride, const cc_detect_params* p, std::vector<CandOut>* collect,
+                           bool debug) {
+  cc_status stt = ensure_device(d->device);
+  if (stt != CC_OK) return stt;
+  Plan* P = nullptr;
+  stt = build_plan(d, width, height, *p, &P);
+  if (stt != CC_OK) return stt;
+  for (int f0 = 0; f0 < n_frames; f0 += d->max_batch) {
+    const int nf = std::min(d->max_batch, n_frames - f0);
+    const uint8_t* dptr;
+    size_t rs = row_stride, fs = frame_stride;
+    if (on_device) {
+      dptr = frames + (size_t)f0 * frame_stride;
+    } else {
+      rs = (size_t)align_up(width, 4);
+      fs = rs * (size_t)height;
+      CC_HIP(d->d_frames.ensure(fs * (size_t)d->max_batch));
+      for (int f = 0; f < nf; f++)
+        CC_HIP(hipMemcpy2DAsync(d->d_frames.p + (size_t)f * fs, rs, frames + (size_t)(f0 + f) * frame_stride, row_stride,
+                                (size_t)width, (size_t)height, hipMemcpyHostToDevice, d->stream));
+      dptr = d->d_frames.p;
+    }
+    for (;;) {
+      stt = run_device_pass(d, P, dptr, nf, rs, fs, debug);
+      if (stt != CC_OK) return stt;
+      if (!collect) break;
+      int counts[2] = {0, 0};
+      CC_HIP(hipMemcpyAsync(counts, d->d_counts.p, sizeof(counts), hipMemcpyDeviceToHost, d->stream));
+      CC_HIP(hipStreamSynchronize(d->stream));
+      if (counts[0] > d->cand_cap) {  // candidate list overflowed: grow and redo this pass
+        d->cand_cap = counts[0] + counts[0] / 2;
+        d->d_cands.release();
+        d->d_out.release();
+        continue;
+      }
+      const size_t o = collect->size();
+      collect->resize(o + (size_t)counts[1]);
+      if (counts[1] > 0) {
+        CC_HIP(hipMemcpyAsync(collect->data() + o, d->d_out.p, (size_t)counts[1] * sizeof(CandOut), hipMemcpyDeviceToHost,
+                              d->stream));
+        CC_HIP(hipStreamSynchronize(d->stream));
+        for (size_t i = o; i < collect->size(); i++) (*collect)[i].frame += f0;
+      }
+      break;
+    }
+  }
+  if (d->profiling) {
+    CC_HIP(hipStreamSynchronize(d->stream));
+    collect_events(d);
+  }
+  return CC_OK;
+}
+
+static void sort_candidates(std::vector<CandOut>& v) {
+  std::sort(v.begin(), v.end(), [](const CandOut& a, const CandOut& b) {
+    if (a.frame != b.frame) return a.frame < b.frame;
+    if (a.scale != b.scale) return a.scale < b.scale;
+    if (a.gy != b.gy) return a.gy < b.gy;
+    return a.gx < b.gx;
+  });
+}
+
+}  // namespace ccamd
+
+extern "C" {
+
+int cc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_detector** out) {
+  if (!c || !out) return set_error(CC_ERR_INVALID_ARG, "cc_detector_create: null argument");
+  *out = nullptr;
+  if (max_batch < 1 || max_batch > 4096) return set_error(CC_ERR_INVALID_ARG, "cc_detector_create: max_batch %d out of range", max_batch);
+  if (c->m.max_nodes_per_tree != 1)
+    return set_error(CC_ERR_UNSUPPORTED, "cc_detector_create: cascades with trees deeper than stumps are not implemented on the device yet");
+  if (c->m.has_tilted)
+    return set_error(CC_ERR_UNSUPPORTED, "cc_detector_create: tilted Haar features are not implemented in the detection kernels yet");
+  cc_status st = ensure_device(device);
+  if (st != CC_OK) return st;
+  std::unique_ptr<cc_detector> d(new cc_detector());
+  d->m = c->m;
+  d->device = device;
+  d->max_batch = max_batch;
+  CC_HIP(hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking));
+  d->stream = d->own_stream;
+  const TileGeom<1> G1(d->m.win_w, d->m.win_h);
+  const TileGeom<2> G2(d->m.win_w, d->m.win_h);
+  d->lds = (size_t)std::max(G1.words(), G2.words()) * 4;
+  if (d->lds > 160 * 1024 - 256)
+    return set_error(CC_ERR_UNSUPPORTED, "cc_detector_create: %dx%d window needs %zu bytes of LDS per tile (limit 160 KiB)",
+                     d->m.win_w, d->m.win_h, d->lds);
+  const bool haar = d->m.feature_type == CC_FEATURE_HAAR;
+  if (d->lds > 64 * 1024) {
+    if (haar)
+      CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_haar), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds));
+    else
+      CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_lbp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds));
+  }
+  std::vector<int> ntrees(d->m.stage_ntrees.begin(), d->m.stage_ntrees.end());
+  CC_HIP(d->d_stage_ntrees.upload(ntrees, d->stream));
+  CC_HIP(d->d_stage_thr.upload(d->m.stage_threshold, d->stream));
+  if (haar) {
+    std::vector<HaarStumpDev> s1, s2;
+    build_haar_stumps<1>(d->m, s1);
+    build_haar_stumps<2>(d->m, s2);
+    CC_HIP(d->d_haar1.upload(s1, d->stream));
+    CC_HIP(d->d_haar2.upload(s2, d->stream));
+    CC_HIP(hipStreamSynchronize(d->stream));
+  } else {
+    std::vector<LbpStumpDev> s1, s2;
+    build_lbp_stumps<1>(d->m, s1);
+    build_lbp_stumps<2>(d->m, s2);
+    CC_HIP(d->d_lbp1.upload(s1, d->stream));
+    CC_HIP(d->d_lbp2.upload(s2, d->stream));
+    CC_HIP(hipStreamSynchronize(d->stream));
+  }
+  *out = d.release();
+  return CC_OK;
+}
+
+void cc_detector_destroy(cc_detector* d) {
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  delete d;
+}
+
+cc_status cc_detector_set_stream(cc_detector* d, void* hip_stream) {
+  if (!d) return set_error(CC_ERR_INVALID_ARG, "cc_detector_set_stream: null detector");
+  d->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : d->own_stream;
+  return CC_OK;
+}
+
+cc_status cc_detector_set_profiling(cc_detector* d, int enabled) {
+  if (!d) return set_error(CC_ERR_INVALID_ARG, "cc_detector_set_profiling: null detector");
+  d->profiling = enabled != 0;
+  return CC_OK;
+}
+
+cc_status cc_detector_get_timings(cc_detector* d, cc_detector_timings* t, int reset) {
+  if (!d || !t) return set_error(CC_ERR_INVALID_ARG, "cc_detector_get_timings: null argument");
+  *t = d->tm;
+  if (reset) std::memset(&d->tm, 0, sizeof(d->tm));
+  return CC_OK;
+}
+
+cc_status cc_detect_batch_device_only(cc_detector* d, const uint8_t* frames, int on_device, int n_frames, int width, int height,
+                                      size_t row_stride, size_t frame_stride, const cc_detect_params* p) {
+  cc_status st = check_frame_args(d, frames, n_frames, width, height, row_stride, p, "cc_detect_batch_device_only");
+  if (st != CC_OK) return st;
+  return run_batch(d, frames, on_device, n_frames, width, height, row_stride, frame_stride, p, nullptr, false);
+}
+
+cc_status cc_detect_batch(cc_detector* d, const uint8_t* frames, int on_device, int n_frames, int width, int height,
+                          size_t row_stride, size_t frame_stride, const cc_detect_params* p, cc_rect* out, int cap,
+                          int32_t* offsets) {
+  cc_status st = check_frame_args(d, frames, n_frames, width, height, row_stride, p, "cc_detect_batch");
+  if (st != CC_OK) return st;
+  if (!offsets || (cap > 0 && !out) || cap < 0) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch: bad output buffers");
+  std::vector<CandOut> cands;
+  st = run_batch(d, frames, on_device, n_frames, width, height, row_stride, frame_stride, p, &cands, false);
+  if (st != CC_OK) return st;
+  sort_candidates(cands);
+  size_t i = 0;
+  long long total = 0;
+  std::vector<cc_rect> rects;
+  for (int f = 0; f < n_frames; f++) {
+    offsets[f] = (int32_t)total;
+    rects.clear();
+    for (; i < cands.size() && cands[i].frame == f; i++) rects.push_back(cc_rect{cands[i].x, cands[i].y, cands[i].w, cands[i].h});
+    group_rectangles(rects, p->min_neighbors, 0.2);  // GROUP_EPS
+    for (const cc_rect& r : rects) {
+      if (total < cap) out[total] = r;
+      total++;
+    }
+  }
+  offsets[n_frames] = (int32_t)total;
+  if (total > cap) return set_error(CC_ERR_BUFFER_TOO_SMALL, "cc_detect_batch: %lld rectangles, capacity %d", total, cap);
+  return CC_OK;
+}
+
+cc_status cc_detect_multiscale(cc_detector* d, const uint8_t* gray, int width, int height, size_t row_stride,
+                               const cc_detect_params* p, cc_rect* out, int cap, int* n) {
+  if (!n) return set_error(CC_ERR_INVALID_ARG, "cc_detect_multiscale: null count pointer");
+  int32_t offsets[2] = {0, 0};
+  cc_status st = cc_detect_batch(d, gray, 0, 1, width, height, row_stride, row_stride * (size_t)height, p, out, cap, offsets);
+  if (st == CC_OK || st == CC_ERR_BUFFER_TOO_SMALL) *n = offsets[1];
+  return st;
+}
+
+cc_status cc_detect_raw(cc_detector* d, const uint8_t* gray, int width, int height, size_t row_stride, const cc_detect_params* p,
+                        int32_t* cand, int cap, int* n) {
+  cc_status st = check_frame_args(d, gray, 1, width, height, row_stride, p, "cc_detect_raw");
+  if (st != CC_OK) return st;
+  if (!n || (cap > 0 && !cand)) return set_error(CC_ERR_INVALID_ARG, "cc_detect_raw: bad output buffers");
+  std::vector<CandOut> cands;
+  st = run_batch(d, gray, 0, 1, width, height, row_stride, row_stride * (size_t)height, p, &cands, false);
+  if (st != CC_OK) return st;
+  sort_candidates(cands);
+  *n = (int)cands.size();
+  for (int i = 0; i < (int)cands.size() && i < cap; i++) {
+    const CandOut& c = cands[i];
+    const int32_t v[7] = {c.scale, c.gx, c.gy, c.x, c.y, c.w, c.h};
+    std::memcpy(cand + 7 * (size_t)i, v, sizeof(v));
+  }
+  if ((int)cands.size() > cap) return set_error(CC_ERR_BUFFER_TOO_SMALL, "cc_detect_raw: %zu candidates, capacity %d", cands.size(), cap);
+  return CC_OK;
+}
+
+cc_status cc_detect_debug_windows(cc_detector* d, const uint8_t* gray, int width, int height, size_t row_stride,
+                                  const cc_detect_params* p, int32_t* codes, double* sums, uint8_t* visited, int64_t cap,
+                                  int64_t* n_windows) {
+  cc_status st = check_frame_args(d, gray, 1, width, height, row_stride, p, "cc_detect_debug_windows");
+  if (st != CC_OK) return st;
+  if (!n_windows) return set_error(CC_ERR_INVALID_ARG, "cc_detect_debug_windows: null count pointer");
+  std::vector<CandOut> cands;
+  st = run_batch(d, gray, 0, 1, width, height, row_stride, row_stride * (size_t)height, p, &cands, true);
+  if (st != CC_OK) return st;
+  Plan* P = nullptr;
+  st = build_plan(d, width, height, *p, &P);
+  if (st != CC_OK) return st;
+  *n_windows = P->windows;
+  if (P->windows > cap) return set_error(CC_ERR_BUFFER_TOO_SMALL, "cc_detect_debug_windows: %lld windows, capacity %lld", P->windows, (long long)cap);
+  const size_t nw = (size_t)P->windows;
+  if (nw) {
+    if (codes) CC_HIP(hipMemcpy(codes, d->d_dbg_codes.p, nw * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (sums) CC_HIP(hipMemcpy(sums, d->d_dbg_sums.p, nw * sizeof(double), hipMemcpyDeviceToHost));
+    if (visited) CC_HIP(hipMemcpy(visited, d->d_dbg_visited.p, nw, hipMemcpyDeviceToHost));
+  }
+  return CC_OK;
+}
+
+// ---- building blocks -------------------------------------------------------------------------------------------
+cc_status cc_resize_linear_exact_u8(int device, const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, int dw, int dh,
+                                    size_t dstride) {
+  if (!src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1 || sstride < (size_t)sw || dstride < (size_t)dw)
+    return set_error(CC_ERR_INVALID_ARG, "cc_resize_linear_exact_u8: bad argument");
+  cc_status st = ensure_device(device);
+  if (st != CC_OK) return st;
+  ScaleDev S;
+  std::memset(&S, 0, sizeof(S));
+  S.w = dw;
+  S.h = dh;
+  S.pitch8 = align_up(dw, 4);
+  AxisTaps tx, ty;
+  linear_exact_taps(sw, dw, tx);
+  linear_exact_taps(sh, dh, ty);
+  std::vector<ScaleDev> sd{S};
+  const int nblk = ((S.pitch8 / 4) * dh + 255) / 256;
+  std::vector<int> first{0, nblk};
+  DevBuf<ScaleDev> d_sd;
+  DevBuf<int> d_first, d_xofs, d_yofs;
+  DevBuf<uint16_t> d_xw1, d_yw1;
+  DevBuf<uint8_t> d_src, d_dst;
+  const size_t spitch = (size_t)align_up(sw, 4);
+  CC_HIP(d_sd.upload(sd, nullptr));
+  CC_HIP(d_first.upload(first, nullptr));
+  CC_HIP(d_xofs.upload(tx.ofs, nullptr));
+  CC_HIP(d_yofs.upload(ty.ofs, nullptr));
+  CC_HIP(d_xw1.upload(tx.w1, nullptr));
+  CC_HIP(d_yw1.upload(ty.w1, nullptr));
+  CC_HIP(d_src.ensure(spitch * sh));
+  CC_HIP(d_dst.ensure((size_t)S.pitch8 * dh));
+  CC_HIP(hipMemcpy2D(d_src.p, spitch, src, sstride, sw, sh, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_resize, dim3(nblk, 1), dim3(256), 0, nullptr, d_src.p, spitch, (size_t)0, sw, sh, d_dst.p, (size_t)0,
+                     d_sd.p, 1, d_first.p, d_xofs.p, d_xw1.p, d_yofs.p, d_yw1.p);
+  CC_HIP(hipGetLastError());
+  CC_HIP(hipMemcpy2D(dst, dstride, d_dst.p, S.pitch8, dw, dh, hipMemcpyDeviceToHost));
+  return CC_OK;
+}
+
+cc_status cc_integral_u8(int device, const uint8_t* img, int width, int height, size_t row_stride, int32_t* sum, int32_t* sqsum,
+                         int32_t* tilted) {
+  if (!img || width < 1 || height < 1 || row_stride < (size_t)width) return set_error(CC_ERR_INVALID_ARG, "cc_integral_u8: bad argument");
+  cc_status st = ensure_device(device);
+  if (st != CC_OK) return st;
+  ScaleDev S;
+  std::memset(&S, 0, sizeof(S));
+  S.w = width;
+  S.h = height;
+  S.pitch8 = align_up(width, 4);
+  S.pitchI = align_up(width + 1, 4);
+  std::vector<ScaleDev> sd{S};
+  std::vector<int> row_first{0, height + 1}, col_first{0, (S.pitchI / 4 + 63) / 64};
+  DevBuf<ScaleDev> d_sd;
+  DevBuf<int> d_row_first, d_col_first;
+  DevBuf<uint8_t> d_img;
+  DevBuf<int32_t> d_int, d_tilt;
+  const size_t elems = (size_t)S.pitchI * (height + 1);
+  CC_HIP(d_sd.upload(sd, nullptr));
+  CC_HIP(d_row_first.upload(row_first, nullptr));
+  CC_HIP(d_col_first.upload(col_first, nullptr));
+  CC_HIP(d_img.ensure((size_t)S.pitch8 * height));
+  CC_HIP(d_int.ensure(elems * 2));
+  CC_HIP(hipMemcpy2D(d_img.p, S.pitch8, img, row_stride, width, height, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_integral_rows<true>, dim3((height + 1 + 3) / 4, 1), dim3(256), 0, nullptr, d_img.p, (size_t)0, d_int.p,
+                     elems, 2, d_sd.p, 1, d_row_first.p, height + 1);
+  hipLaunchKernelGGL(k_integral_cols, dim3(col_first[1], 1, 2), dim3(64), 0, nullptr, d_int.p, elems, 2, d_sd.p, 1, d_col_first.p);
+  CC_HIP(hipGetLastError());
+  const size_t opitch = (size_t)(width + 1) * 4;
+  if (sum) CC_HIP(hipMemcpy2D(sum, opitch, d_int.p, (size_t)S.pitchI * 4, opitch, height + 1, hipMemcpyDeviceToHost));
+  if (sqsum) CC_HIP(hipMemcpy2D(sqsum, opitch, d_int.p + elems, (size_t)S.pitchI * 4, opitch, height + 1, hipMemcpyDeviceToHost));
+  if (tilted) {
+    CC_HIP(d_tilt.ensure(elems));
+    hipLaunchKernelGGL(k_tilted_from_sum, dim3((width + 1 + 63) / 64, height + 1), dim3(64), 0, nullptr, d_int.p, S.pitchI, width,
+                       height, d_tilt.p, S.pitchI);
+    CC_HIP(hipGetLastError());
+    CC_HIP(hipMemcpy2D(tilted, opitch, d_tilt.p, (size_t)S.pitchI * 4, opitch, height + 1, hipMemcpyDeviceToHost));
+  }
+  return CC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,670 @@
+// Training-side feature evaluator on gfx950: batched setImage (per-sample integral / tilted integral / norm factor),
+// bulk operator() over (feature range x samples) and stump-cascade predict over stored samples.
+// Replaces CvHaarEvaluator / CvLBPEvaluator (traincascade/lib/include/haarfeatures.h:61-122, lbpfeatures.h:37-83,
+// traincascade/lib/src/haarfeatures.cpp:89-114, lbpfeatures.cpp:15-28) behind section 4 of the C ABI.
+//
+// Data layout in HBM: sum / tilted are [max_samples][(W+1)*(H+1)] int32, one sample per row exactly like the
+// reference's `sum` / `tilted` Mats; normfactor is [max_samples] float. The batch kernel stages a tile of samples
+// TRANSPOSED into LDS ([integral entry][sample]) so that a wavefront's lanes (samples) hit distinct banks, and writes
+// out[(fi - fi_begin) * n_samples + s] with the sample index fastest (coalesced row segments).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+#include "cc_internal.h"
+
+namespace ccamd {
+
+#define CC_HIP(expr)                                                                                         \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) return set_error(CC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                           __FILE__, __LINE__);                                              \
+  } while (0)
+
+// Haar feature with the reference's fastRect offsets (row stride W+1) — haarfeatures.cpp:266-309.
+struct HaarFeatDev {
+  int p[3][4];
+  float w[3];
+  int tilted;
+};
+struct LbpFeatDev {
+  int p[16];
+};
+
+// ------------------------------------------------------------------------------------------------
+// setImage for a batch: one 64-thread block per sample.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_set_images(const uint8_t* __restrict__ imgs, int W, int H, int first_idx,
+                                                   int32_t* __restrict__ sum, int32_t* __restrict__ tilted,
+                                                   float* __restrict__ normfactor, int want_norm) {
+  extern __shared__ int32_t lds[];  // row prefix sums [H][W+1]
+  const int cols = (W + 1) * (H + 1), sw = W + 1;
+  const int i = blockIdx.x;
+  const uint8_t* img = imgs + (size_t)i * W * H;
+  int32_t* s = sum + (size_t)(first_idx + i) * cols;
+  for (int y = threadIdx.x; y < H; y += 64) {
+    int acc = 0;
+    lds[y * sw] = 0;
+    for (int x = 0; x < W; x++) {
+      acc += img[y * W + x];
+      lds[y * sw + x + 1] = acc;
+    }
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x <= W; x += 64) {
+    int acc = 0;
+    s[x] = 0;
+    for (int y = 0; y < H; y++) {
+      acc += lds[y * sw + x];
+      s[(y + 1) * sw + x] = acc;
+    }
+  }
+  if (tilted) {
+    int32_t* t = tilted + (size_t)(first_idx + i) * cols;
+    for (int e = threadIdx.x; e < cols; e += 64) {
+      const int Y = e / sw, X = e - Y * sw;
+      int acc = 0;
+      for (int y = 0; y < Y; y++) {
+        const int half = Y - y - 1;
+        const int x0 = max(X - 1 - half, 0), x1 = min(X - 1 + half, W - 1);
+        if (x1 >= x0) acc += lds[y * sw + x1 + 1] - lds[y * sw + x0];
+      }
+      t[e] = acc;
+    }
+  }
+  if (want_norm) {
+    // calcNormFactor (features.cpp:13-25): sums over normrect (1,1,W-2,H-2); the reference's double sqsum integral
+    // holds exact integers, so the 4-corner difference equals the exact integer sum of squares computed here.
+    long long sq = 0;
+    int sm = 0;
+    for (int e = threadIdx.x; e < (W - 2) * (H - 2); e += 64) {
+      const int y = 1 + e / (W - 2), x = 1 + e % (W - 2);
+      const int p = img[y * W + x];
+      sm += p;
+      sq += p * p;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      sm += __shfl_xor(sm, d);
+      sq += __shfl_xor(sq, d);
+    }
+    if (threadIdx.x == 0) {
+      const double area = (double)((W - 2) * (H - 2));
+      normfactor[first_idx + i] = (float)sqrt((double)(area * (double)sq - (double)sm * (double)sm));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bulk operator(): block = 256 threads, a tile of S samples staged transposed into LDS, loops over a feature chunk.
+// lane -> (feature sub-index, sample): s = lane % S.
+// ------------------------------------------------------------------------------------------------
+struct BatchArgs {
+  const int32_t* sum;
+  const int32_t* tilted;
+  const float* normfactor;
+  const int32_t* sample_idx;  // optional
+  int n_samples;
+  int cols;
+  int S;                      // samples per tile (power of two, <= 64)
+  int feat_begin, feat_end;   // indices into the feature table
+  int feats_per_block;
+  const void* feats;
+  float* out;                 // [feat_end - feat_begin][n_samples]
+  int normalized;             // Haar: divide by normfactor (operator()) or not (Feature::calc)
+  int use_tilted;
+};
+
+template <bool HAAR>
+__global__ __launch_bounds__(256) void k_eval_batch(BatchArgs A) {
+  extern __shared__ int32_t lds[];  // [cols][S] (+ [cols][S] tilted)
+  const int S = A.S;
+  const int s0 = blockIdx.x * S;
+  int32_t* lsum = lds;
+  int32_t* ltil = lds + (size_t)A.cols * S;
+  // stage: consecutive threads read consecutive entries of one sample (coalesced), write transposed
+  for (int e = threadIdx.x; e < A.cols * S; e += 256) {
+    const int s = e / A.cols, p = e - s * A.cols;
+    int v = 0, t = 0;
+    if (s0 + s < A.n_samples) {
+      const int si = A.sample_idx ? A.sample_idx[s0 + s] : s0 + s;
+      v = A.sum[(size_t)si * A.cols + p];
+      if (HAAR && A.use_tilted) t = A.tilted[(size_t)si * A.cols + p];
+    }
+    lsum[p * S + s] = v;
+    if (HAAR && A.use_tilted) ltil[p * S + s] = t;
+  }
+  __syncthreads();
+  const int s = threadIdx.x % S;
+  const int fsub = threadIdx.x / S, fpar = 256 / S;
+  const bool valid = s0 + s < A.n_samples;
+  float nf = 1.f;
+  if (HAAR && A.normalized && valid) nf = A.normfactor[A.sample_idx ? A.sample_idx[s0 + s] : s0 + s];
+  const int f0 = A.feat_begin + blockIdx.y * A.feats_per_block;
+  const int f1 = min(f0 + A.feats_per_block, A.feat_end);
+  for (int f = f0 + fsub; f < f1; f += fpar) {
+    float val;
+    if (HAAR) {
+      const HaarFeatDev F = reinterpret_cast<const HaarFeatDev*>(A.feats)[f];
+      const int32_t* img = (F.tilted ? ltil : lsum) + s;
+      float ret = F.w[0] * (float)(img[F.p[0][0] * S] - img[F.p[0][1] * S] - img[F.p[0][2] * S] + img[F.p[0][3] * S]) +
+                  F.w[1] * (float)(img[F.p[1][0] * S] - img[F.p[1][1] * S] - img[F.p[1][2] * S] + img[F.p[1][3] * S]);
+      if (F.w[2] != 0.0f)
+        ret += F.w[2] * (float)(img[F.p[2][0] * S] - img[F.p[2][1] * S] - img[F.p[2][2] * S] + img[F.p[2][3] * S]);
+      val = A.normalized ? (nf == 0.0f ? 0.0f : ret / nf) : ret;
+    } else {
+      const LbpFeatDev F = reinterpret_cast<const LbpFeatDev*>(A.feats)[f];
+      const int32_t* b = lsum + s;
+      int p[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) p[j] = b[F.p[j] * S];
+      const int c = p[5] - p[6] - p[9] + p[10];
+      const int code = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
+                       (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
+                       (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
+                       (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
+      val = (float)code;
+    }
+    if (valid) A.out[(size_t)(f - A.feat_begin) * A.n_samples + s0 + s] = val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Training-side stump-cascade predict: one thread per sample (boost.cpp:461-477, o_cvcascadeboosttree.cpp:16-39).
+// ------------------------------------------------------------------------------------------------
+struct PredictArgs {
+  const int32_t* sum;
+  const int32_t* tilted;
+  const float* normfactor;
+  const int32_t* sample_idx;
+  int n_samples, cols;
+  int nstages;
+  const int* stage_ntrees;
+  const float* stage_thr;  // threshold - CV_THRESHOLD_EPS
+  const void* feats;       // per stump feature, fastRect offsets
+  const float* stump_thr;
+  const float* stump_left;
+  const float* stump_right;
+  const int* subsets;      // 8 words per stump (LBP)
+  uint8_t* out;
+};
+
+template <bool HAAR>
+__global__ __launch_bounds__(64) void k_predict(PredictArgs A) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= A.n_samples) return;
+  const int si = A.sample_idx ? A.sample_idx[s] : s;
+  const int32_t* img = A.sum + (size_t)si * A.cols;
+  const int32_t* timg = A.tilted ? A.tilted + (size_t)si * A.cols : img;
+  const float nf = HAAR ? A.normfactor[si] : 1.f;
+  int k = 0;
+  uint8_t pass = 1;
+  for (int st = 0; st < A.nstages && pass; st++) {
+    double acc = 0;
+    const int nt = A.stage_ntrees[st];
+    for (int i = 0; i < nt; i++, k++) {
+      if (HAAR) {
+        const HaarFeatDev F = reinterpret_cast<const HaarFeatDev*>(A.feats)[k];
+        const int32_t* b = F.tilted ? timg : img;
+        float ret = F.w[0] * (float)(b[F.p[0][0]] - b[F.p[0][1]] - b[F.p[0][2]] + b[F.p[0][3]]) +
+                    F.w[1] * (float)(b[F.p[1][0]] - b[F.p[1][1]] - b[F.p[1][2]] + b[F.p[1][3]]);
+        if (F.w[2] != 0.0f) ret += F.w[2] * (float)(b[F.p[2][0]] - b[F.p[2][1]] - b[F.p[2][2]] + b[F.p[2][3]]);
+        const float val = nf == 0.0f ? 0.0f : ret / nf;
+        acc += (double)(val <= A.stump_thr[k] ? A.stump_left[k] : A.stump_right[k]);
+      } else {
+        const LbpFeatDev F = reinterpret_cast<const LbpFeatDev*>(A.feats)[k];
+        int p[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) p[j] = img[F.p[j]];
+        const int c = p[5] - p[6] - p[9] + p[10];
+        const int code = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
+                         (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
+                         (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
+                         (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
+        const int word = A.subsets[(size_t)k * 8 + (code >> 5)];
+        acc += (double)((word & (1 << (code & 31))) ? A.stump_left[k] : A.stump_right[k]);
+      }
+    }
+    if (acc < (double)A.stage_thr[st]) pass = 0;
+  }
+  A.out[s] = pass;
+}
+
+template <class T>
+struct EBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~EBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t ensure(size_t count) {
+    if (count <= n) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+};
+
+static void haar_to_dev(const HaarFeature& f, int step, HaarFeatDev& d) {
+  std::memset(&d, 0, sizeof(d));
+  d.tilted = f.tilted;
+  for (int j = 0; j < 3; j++) d.w[j] = f.w[j];
+  for (int j = 0; j < 3; j++) {
+    if (f.w[j] == 0.0f) break;  // offsets stay 0 from the first zero weight on (haarfeatures.cpp:292-308)
+    const int x = f.r[j][0], y = f.r[j][1], w = f.r[j][2], h = f.r[j][3];
+    if (!f.tilted) {  // CV_SUM_OFFSETS, traincascade_features.h:40-50
+      d.p[j][0] = x + step * y;
+      d.p[j][1] = x + w + step * y;
+      d.p[j][2] = x + step * (y + h);
+      d.p[j][3] = x + w + step * (y + h);
+    } else {  // CV_TILTED_OFFSETS, traincascade_features.h:54-63
+      d.p[j][0] = x + step * y;
+      d.p[j][1] = x - h + step * (y + h);
+      d.p[j][2] = x + w + step * (y + w);
+      d.p[j][3] = x + w - h + step * (y + w + h);
+    }
+  }
+}
+
+static void lbp_to_dev(const int32_t* r, int step, LbpFeatDev& d) {  // lbpfeatures.cpp:53-63
+  for (int rr = 0; rr < 4; rr++)
+    for (int cc = 0; cc < 4; cc++) d.p[4 * rr + cc] = (r[0] + cc * r[2]) + step * (r[1] + rr * r[3]);
+}
+
+}  // namespace ccamd
+
+using namespace ccamd;
+
+struct cc_evaluator {
+  int type = 0, mode = 0, W = 0, H = 0, max_samples = 0, device = 0, cols = 0;
+  bool use_tilted = false;
+  std::vector<HaarFeature> haar;
+  std::vector<int32_t> lbp;
+  std::vector<float> cls;
+  int nfeat = 0;
+  hipStream_t stream = nullptr;
+  EBuf<int32_t> d_sum, d_tilted;
+  EBuf<float> d_nf;
+  EBuf<HaarFeatDev> d_haar;
+  EBuf<LbpFeatDev> d_lbp;
+  // scratch (guarded by mu: the calc entry points may be called concurrently)
+  std::mutex mu;
+  EBuf<uint8_t> d_imgs;
+  EBuf<int32_t> d_idx;
+  EBuf<float> d_out;
+  EBuf<HaarFeatDev> d_custom;
+  EBuf<uint8_t> d_pred;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  double last_ms = 0;
+  int S = 16;
+  ~cc_evaluator() {
+    if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_b) (void)hipEventDestroy(ev_b);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace ccamd {
+
+static cc_status eval_device(cc_evaluator* e) {
+  int n = 0;
+  hipError_t err = hipGetDeviceCount(&n);
+  if (err != hipSuccess || n <= 0)
+    return set_error(CC_ERR_NO_DEVICE, "no usable HIP device (%s); this library has no CPU fallback",
+                     err != hipSuccess ? hipGetErrorString(err) : "device count is 0");
+  if (e->device < 0 || e->device >= n) return set_error(CC_ERR_INVALID_ARG, "device %d out of range (devices: %d)", e->device, n);
+  CC_HIP(hipSetDevice(e->device));
+  return CC_OK;
+}
+
+// Launches k_eval_batch over `feats` [fb, fe) for ns samples into d_out_ptr (device). Caller holds e->mu.
+static cc_status launch_batch(cc_evaluator* e, bool haar, const void* feats, int fb, int fe, const int32_t* d_idx, int ns,
+                              float* d_out_ptr, int normalized) {
+  BatchArgs A;
+  A.sum = e->d_sum.p;
+  A.tilted = e->use_tilted ? e->d_tilted.p : nullptr;
+  A.normfactor = e->d_nf.p;
+  A.sample_idx = d_idx;
+  A.n_samples = ns;
+  A.cols = e->cols;
+  A.S = e->S;
+  A.feat_begin = fb;
+  A.feat_end = fe;
+  A.feats = feats;
+  A.out = d_out_ptr;
+  A.normalized = normalized;
+  A.use_tilted = e->use_tilted ? 1 : 0;
+  const int nfe = fe - fb;
+  const int tiles = (ns + e->S - 1) / e->S;
+  // enough feature chunks to fill the chip, but each block amortises its tile load over >= 512 features
+  int chunks = std::max(1, std::min((nfe + 511) / 512, std::max(1, 8192 / std::max(tiles, 1))));
+  A.feats_per_block = (nfe + chunks - 1) / chunks;
+  chunks = (nfe + A.feats_per_block - 1) / A.feats_per_block;
+  const size_t lds = (size_t)e->cols * e->S * 4 * (haar && e->use_tilted ? 2 : 1);
+  (void)hipEventRecord(e->ev_a, e->stream);
+  if (haar)
+    hipLaunchKernelGGL(k_eval_batch<true>, dim3(tiles, chunks), dim3(256), lds, e->stream, A);
+  else
+    hipLaunchKernelGGL(k_eval_batch<false>, dim3(tiles, chunks), dim3(256), lds, e->stream, A);
+  (void)hipEventRecord(e->ev_b, e->stream);
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
+static cc_status upload_indices(cc_evaluator* e, const int32_t* sample_idx, int ns, const int32_t** d_idx) {
+  *d_idx = nullptr;
+  if (!sample_idx) {
+    if (ns > e->max_samples) return set_error(CC_ERR_OUT_OF_RANGE, "n_samples %d exceeds max_samples %d", ns, e->max_samples);
+    return CC_OK;
+  }
+  for (int i = 0; i < ns; i++)
+    if (sample_idx[i] < 0 || sample_idx[i] >= e->max_samples)
+      return set_error(CC_ERR_OUT_OF_RANGE, "sample index %d out of range (max_samples %d)", sample_idx[i], e->max_samples);
+  CC_HIP(e->d_idx.ensure((size_t)ns));
+  CC_HIP(hipMemcpyAsync(e->d_idx.p, sample_idx, (size_t)ns * 4, hipMemcpyHostToDevice, e->stream));
+  *d_idx = e->d_idx.p;
+  return CC_OK;
+}
+
+}  // namespace ccamd
+
+extern "C" {
+
+cc_status cc_eval_create(int feature_type, int haar_mode, int win_w, int win_h, int max_samples, int device, cc_evaluator** out) {
+  if (!out) return set_error(CC_ERR_INVALID_ARG, "cc_eval_create: null output");
+  *out = nullptr;
+  if (feature_type == CC_FEATURE_HOG) return set_error(CC_ERR_UNSUPPORTED, "cc_eval_create: HOG is outside the accelerated path");
+  if (feature_type != CC_FEATURE_HAAR && feature_type != CC_FEATURE_LBP) return set_error(CC_ERR_INVALID_ARG, "cc_eval_create: unknown feature type %d", feature_type);
+  if (max_samples <= 0) return set_error(CC_ERR_INVALID_ARG, "cc_eval_create: maxSampleCount must be > 0");  // features.cpp:75
+  if (win_w < 3 || win_h < 3 || win_w > 256 || win_h > 256) return set_error(CC_ERR_INVALID_ARG, "cc_eval_create: window %dx%d out of range", win_w, win_h);
+  if (feature_type == CC_FEATURE_HAAR && (haar_mode < CC_HAAR_BASIC || haar_mode > CC_HAAR_ALL))
+    return set_error(CC_ERR_INVALID_ARG, "cc_eval_create: unknown Haar mode %d", haar_mode);
+  std::unique_ptr<cc_evaluator> e(new cc_evaluator());
+  e->type = feature_type;
+  e->mode = haar_mode;
+  e->W = win_w;
+  e->H = win_h;
+  e->max_samples = max_samples;
+  e->device = device;
+  e->cols = (win_w + 1) * (win_h + 1);
+  e->use_tilted = feature_type == CC_FEATURE_HAAR && haar_mode == CC_HAAR_ALL;
+  cc_status st = eval_device(e.get());
+  if (st != CC_OK) return st;
+  e->cls.assign((size_t)max_samples, 0.f);
+  // samples per LDS tile: largest power of two that keeps the tile within 64 KiB
+  const size_t per_sample = (size_t)e->cols * 4 * (e->use_tilted ? 2 : 1);
+  int S = 64;
+  while (S > 1 && per_sample * S > 64 * 1024) S >>= 1;
+  if (per_sample * S > 64 * 1024) return set_error(CC_ERR_UNSUPPORTED, "cc_eval_create: window %dx%d too large for the LDS tile", win_w, win_h);
+  e->S = S;
+  CC_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  CC_HIP(hipEventCreate(&e->ev_a));
+  CC_HIP(hipEventCreate(&e->ev_b));
+  CC_HIP(e->d_sum.ensure((size_t)max_samples * e->cols));
+  CC_HIP(hipMemsetAsync(e->d_sum.p, 0, (size_t)max_samples * e->cols * 4, e->stream));
+  if (e->use_tilted) {
+    CC_HIP(e->d_tilted.ensure((size_t)max_samples * e->cols));
+    CC_HIP(hipMemsetAsync(e->d_tilted.p, 0, (size_t)max_samples * e->cols * 4, e->stream));
+  }
+  CC_HIP(e->d_nf.ensure((size_t)max_samples));
+  CC_HIP(hipMemsetAsync(e->d_nf.p, 0, (size_t)max_samples * 4, e->stream));
+  if (feature_type == CC_FEATURE_HAAR) {
+    haar_catalog(win_w, win_h, haar_mode, e->haar);
+    e->nfeat = (int)e->haar.size();
+    std::vector<HaarFeatDev> dev(e->haar.size());
+    for (size_t i = 0; i < dev.size(); i++) haar_to_dev(e->haar[i], win_w + 1, dev[i]);
+    CC_HIP(e->d_haar.ensure(std::max<size_t>(dev.size(), 1)));
+    CC_HIP(hipMemcpy(e->d_haar.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice));
+  } else {
+    lbp_catalog(win_w, win_h, e->lbp);
+    e->nfeat = (int)(e->lbp.size() / 4);
+    std::vector<LbpFeatDev> dev((size_t)e->nfeat);
+    for (int i = 0; i < e->nfeat; i++) lbp_to_dev(&e->lbp[(size_t)i * 4], win_w + 1, dev[i]);
+    CC_HIP(e->d_lbp.ensure(std::max<size_t>(dev.size(), 1)));
+    CC_HIP(hipMemcpy(e->d_lbp.p, dev.data(), dev.size() * sizeof(LbpFeatDev), hipMemcpyHostToDevice));
+  }
+  CC_HIP(hipStreamSynchronize(e->stream));
+  *out = e.release();
+  return CC_OK;
+}
+
+void cc_eval_destroy(cc_evaluator* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  delete e;
+}
+
+int cc_eval_num_features(const cc_evaluator* e) { return e ? e->nfeat : 0; }
+int cc_eval_max_cat_count(const cc_evaluator* e) { return e && e->type == CC_FEATURE_LBP ? 256 : 0; }
+int cc_eval_feature_size(const cc_evaluator* e) { return e ? 1 : 0; }
+const float* cc_eval_labels(const cc_evaluator* e) { return e ? e->cls.data() : nullptr; }
+
+cc_status cc_eval_feature_geometry(const cc_evaluator* e, int fi, int32_t* rects, float* weights, int* tilted) {
+  if (!e || !rects) return set_error(CC_ERR_INVALID_ARG, "cc_eval_feature_geometry: null argument");
+  if (fi < 0 || fi >= e->nfeat) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_feature_geometry: feature %d out of range (%d)", fi, e->nfeat);
+  if (e->type == CC_FEATURE_HAAR) {
+    std::memcpy(rects, e->haar[fi].r, sizeof(int32_t) * 12);
+    if (weights) std::memcpy(weights, e->haar[fi].w, sizeof(float) * 3);
+    if (tilted) *tilted = e->haar[fi].tilted;
+  } else
+    std::memcpy(rects, &e->lbp[(size_t)fi * 4], sizeof(int32_t) * 4);
+  return CC_OK;
+}
+
+cc_status cc_eval_set_images(cc_evaluator* e, const uint8_t* imgs, int n, int first_idx, const uint8_t* labels) {
+  if (!e || (!imgs && n > 0)) return set_error(CC_ERR_INVALID_ARG, "cc_eval_set_images: null argument");
+  if (n < 0 || first_idx < 0 || first_idx + n > e->max_samples)  // features.cpp:87: idx < cls.rows
+    return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_set_images: samples [%d, %d) exceed max_samples %d", first_idx, first_idx + n, e->max_samples);
+  cc_status st = eval_device(e);
+  if (st != CC_OK) return st;
+  if (n == 0) return CC_OK;
+  std::lock_guard<std::mutex> lk(e->mu);
+  const size_t bytes = (size_t)n * e->W * e->H;
+  CC_HIP(e->d_imgs.ensure(bytes));
+  CC_HIP(hipMemcpyAsync(e->d_imgs.p, imgs, bytes, hipMemcpyHostToDevice, e->stream));
+  const size_t lds = (size_t)e->H * (e->W + 1) * 4;
+  hipLaunchKernelGGL(k_set_images, dim3(n), dim3(64), lds, e->stream, e->d_imgs.p, e->W, e->H, first_idx, e->d_sum.p,
+                     e->use_tilted ? e->d_tilted.p : nullptr, e->d_nf.p, e->type == CC_FEATURE_HAAR ? 1 : 0);
+  CC_HIP(hipGetLastError());
+  CC_HIP(hipStreamSynchronize(e->stream));
+  if (labels)
+    for (int i = 0; i < n; i++) e->cls[(size_t)first_idx + i] = (float)labels[i];
+  return CC_OK;
+}
+
+cc_status cc_eval_set_image(cc_evaluator* e, const uint8_t* img, size_t row_stride, uint8_t cls_label, int idx) {
+  if (!e || !img) return set_error(CC_ERR_INVALID_ARG, "cc_eval_set_image: null argument");
+  if (row_stride < (size_t)e->W) return set_error(CC_ERR_INVALID_ARG, "cc_eval_set_image: row stride smaller than the window width");
+  if (idx < 0 || idx >= e->max_samples) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_set_image: idx %d out of range (%d)", idx, e->max_samples);
+  std::vector<uint8_t> packed((size_t)e->W * e->H);
+  for (int y = 0; y < e->H; y++) std::memcpy(&packed[(size_t)y * e->W], img + (size_t)y * row_stride, (size_t)e->W);
+  return cc_eval_set_images(e, packed.data(), 1, idx, &cls_label);
+}
+
+cc_status cc_eval_calc_batch(cc_evaluator* e, int fi_begin, int fi_end, const int32_t* sample_idx, int n_samples, float* out,
+                             int out_on_device) {
+  if (!e || !out) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_batch: null argument");
+  if (fi_begin < 0 || fi_end > e->nfeat || fi_begin > fi_end)
+    return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc_batch: features [%d, %d) out of range (%d)", fi_begin, fi_end, e->nfeat);
+  if (n_samples < 0) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_batch: negative sample count");
+  cc_status st = eval_device(e);
+  if (st != CC_OK) return st;
+  if (fi_begin == fi_end || n_samples == 0) return CC_OK;
+  std::lock_guard<std::mutex> lk(e->mu);
+  const int32_t* d_idx = nullptr;
+  st = upload_indices(e, sample_idx, n_samples, &d_idx);
+  if (st != CC_OK) return st;
+  const bool haar = e->type == CC_FEATURE_HAAR;
+  const void* feats = haar ? (const void*)e->d_haar.p : (const void*)e->d_lbp.p;
+  const size_t total = (size_t)(fi_end - fi_begin) * n_samples;
+  float* dst = out;
+  if (!out_on_device) {
+    CC_HIP(e->d_out.ensure(total));
+    dst = e->d_out.p;
+  }
+  st = launch_batch(e, haar, feats, fi_begin, fi_end, d_idx, n_samples, dst, 1);
+  if (st != CC_OK) return st;
+  if (!out_on_device) CC_HIP(hipMemcpyAsync(out, dst, total * 4, hipMemcpyDeviceToHost, e->stream));
+  CC_HIP(hipStreamSynchronize(e->stream));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_ms = ms;
+  return CC_OK;
+}
+
+cc_status cc_eval_calc(cc_evaluator* e, int fi, int si, float* out) {
+  if (!e || !out) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc: null argument");
+  if (si < 0 || si >= e->max_samples) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc: sample %d out of range (%d)", si, e->max_samples);
+  const int32_t idx = si;
+  return cc_eval_calc_batch(e, fi, fi + 1, &idx, 1, out, 0);
+}
+
+cc_status cc_eval_calc_custom_haar(cc_evaluator* e, const cc_haar_feature* feats, int n_feats, int normalized,
+                                   const int32_t* sample_idx, int n_samples, float* out) {
+  if (!e || !feats || !out) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_custom_haar: null argument");
+  if (e->type != CC_FEATURE_HAAR) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_custom_haar: evaluator is not HAAR");
+  if (n_feats < 0 || n_samples < 0) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_custom_haar: negative count");
+  cc_status st = eval_device(e);
+  if (st != CC_OK) return st;
+  if (n_feats == 0 || n_samples == 0) return CC_OK;
+  std::vector<HaarFeatDev> dev((size_t)n_feats);
+  for (int i = 0; i < n_feats; i++) {
+    HaarFeature f;
+    std::memcpy(f.r, feats[i].r, sizeof(f.r));
+    std::memcpy(f.w, feats[i].w, sizeof(f.w));
+    f.tilted = feats[i].tilted != 0;
+    if (f.tilted && !e->use_tilted) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_custom_haar: tilted feature on an evaluator without tilted integrals (mode != ALL)");
+    for (int j = 0; j < 3; j++) {  // every touched integral entry must lie inside the (W+1)x(H+1) window integral
+      if (f.w[j] == 0.0f) break;
+      const int x = f.r[j][0], y = f.r[j][1], w = f.r[j][2], h = f.r[j][3];
+      bool ok = x >= 0 && y >= 0 && w >= 0 && h >= 0;
+      ok = ok && (f.tilted ? (x - h >= 0 && x + w <= e->W && y + w + h <= e->H) : (x + w <= e->W && y + h <= e->H));
+      if (!ok) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc_custom_haar: rect %d of feature %d leaves the window", j, i);
+    }
+    haar_to_dev(f, e->W + 1, dev[i]);
+  }
+  std::lock_guard<std::mutex> lk(e->mu);
+  const int32_t* d_idx = nullptr;
+  st = upload_indices(e, sample_idx, n_samples, &d_idx);
+  if (st != CC_OK) return st;
+  CC_HIP(e->d_custom.ensure((size_t)n_feats));
+  CC_HIP(hipMemcpyAsync(e->d_custom.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice, e->stream));
+  const size_t total = (size_t)n_feats * n_samples;
+  CC_HIP(e->d_out.ensure(total));
+  st = launch_batch(e, true, e->d_custom.p, 0, n_feats, d_idx, n_samples, e->d_out.p, normalized ? 1 : 0);
+  if (st != CC_OK) return st;
+  CC_HIP(hipMemcpyAsync(out, e->d_out.p, total * 4, hipMemcpyDeviceToHost, e->stream));
+  CC_HIP(hipStreamSynchronize(e->stream));
+  return CC_OK;
+}
+
+cc_status cc_eval_get_sample(cc_evaluator* e, int idx, int32_t* sum, int32_t* tilted, float* normfactor) {
+  if (!e) return set_error(CC_ERR_INVALID_ARG, "cc_eval_get_sample: null evaluator");
+  if (idx < 0 || idx >= e->max_samples) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_get_sample: idx %d out of range", idx);
+  cc_status st = eval_device(e);
+  if (st != CC_OK) return st;
+  if (sum) CC_HIP(hipMemcpy(sum, e->d_sum.p + (size_t)idx * e->cols, (size_t)e->cols * 4, hipMemcpyDeviceToHost));
+  if (tilted) {
+    if (!e->use_tilted) return set_error(CC_ERR_INVALID_ARG, "cc_eval_get_sample: evaluator keeps no tilted integrals (mode != ALL)");
+    CC_HIP(hipMemcpy(tilted, e->d_tilted.p + (size_t)idx * e->cols, (size_t)e->cols * 4, hipMemcpyDeviceToHost));
+  }
+  if (normfactor) {
+    if (e->type != CC_FEATURE_HAAR) return set_error(CC_ERR_INVALID_ARG, "cc_eval_get_sample: LBP evaluator has no norm factor");
+    CC_HIP(hipMemcpy(normfactor, e->d_nf.p + idx, 4, hipMemcpyDeviceToHost));
+  }
+  return CC_OK;
+}
+
+cc_status cc_eval_predict_cascade(cc_evaluator* e, const cc_cascade* c, const int32_t* sample_idx, int n_samples, uint8_t* out) {
+  if (!e || !c || !out) return set_error(CC_ERR_INVALID_ARG, "cc_eval_predict_cascade: null argument");
+  const Cascade& m = c->m;
+  if (m.feature_type != e->type || m.win_w != e->W || m.win_h != e->H)
+    return set_error(CC_ERR_INVALID_ARG, "cc_eval_predict_cascade: cascade (%s %dx%d) does not match the evaluator (%dx%d)",
+                     m.feature_type == CC_FEATURE_HAAR ? "HAAR" : "LBP", m.win_w, m.win_h, e->W, e->H);
+  if (m.max_nodes_per_tree != 1) return set_error(CC_ERR_UNSUPPORTED, "cc_eval_predict_cascade: trees deeper than stumps are not implemented on the device yet");
+  if (m.has_tilted && !e->use_tilted) return set_error(CC_ERR_INVALID_ARG, "cc_eval_predict_cascade: cascade has tilted features but the evaluator keeps no tilted integrals");
+  if (n_samples < 0) return set_error(CC_ERR_INVALID_ARG, "cc_eval_predict_cascade: negative sample count");
+  cc_status st = eval_device(e);
+  if (st != CC_OK) return st;
+  if (n_samples == 0) return CC_OK;
+  std::lock_guard<std::mutex> lk(e->mu);
+  const int32_t* d_idx = nullptr;
+  st = upload_indices(e, sample_idx, n_samples, &d_idx);
+  if (st != CC_OK) return st;
+  const bool haar = e->type == CC_FEATURE_HAAR;
+  const size_t ns = m.stump_feature.size();
+  EBuf<HaarFeatDev> dh;
+  EBuf<LbpFeatDev> dl;
+  EBuf<int> d_ntrees, d_sub;
+  EBuf<float> d_sthr, d_thr, d_left, d_right;
+  std::vector<int> ntrees(m.stage_ntrees.begin(), m.stage_ntrees.end());
+  if (haar) {
+    std::vector<HaarFeatDev> dev(ns);
+    for (size_t i = 0; i < ns; i++) {
+      HaarFeature f;
+      const int fi = m.stump_feature[i];
+      std::memcpy(f.r, &m.haar_rects[(size_t)fi * 12], sizeof(f.r));
+      std::memcpy(f.w, &m.haar_weights[(size_t)fi * 3], sizeof(f.w));
+      f.tilted = m.haar_tilted[fi];
+      haar_to_dev(f, e->W + 1, dev[i]);
+    }
+    CC_HIP(dh.ensure(ns));
+    CC_HIP(hipMemcpy(dh.p, dev.data(), ns * sizeof(HaarFeatDev), hipMemcpyHostToDevice));
+  } else {
+    std::vector<LbpFeatDev> dev(ns);
+    for (size_t i = 0; i < ns; i++) lbp_to_dev(&m.lbp_rects[(size_t)m.stump_feature[i] * 4], e->W + 1, dev[i]);
+    CC_HIP(dl.ensure(ns));
+    CC_HIP(hipMemcpy(dl.p, dev.data(), ns * sizeof(LbpFeatDev), hipMemcpyHostToDevice));
+    CC_HIP(d_sub.ensure(ns * 8));
+    CC_HIP(hipMemcpy(d_sub.p, m.node_subset.data(), ns * 8 * 4, hipMemcpyHostToDevice));
+  }
+  CC_HIP(d_ntrees.ensure(ntrees.size()));
+  CC_HIP(hipMemcpy(d_ntrees.p, ntrees.data(), ntrees.size() * 4, hipMemcpyHostToDevice));
+  CC_HIP(d_sthr.ensure(ntrees.size()));
+  CC_HIP(hipMemcpy(d_sthr.p, m.stage_threshold.data(), ntrees.size() * 4, hipMemcpyHostToDevice));
+  CC_HIP(d_thr.ensure(ns));
+  CC_HIP(hipMemcpy(d_thr.p, m.stump_threshold.data(), ns * 4, hipMemcpyHostToDevice));
+  CC_HIP(d_left.ensure(ns));
+  CC_HIP(hipMemcpy(d_left.p, m.stump_left.data(), ns * 4, hipMemcpyHostToDevice));
+  CC_HIP(d_right.ensure(ns));
+  CC_HIP(hipMemcpy(d_right.p, m.stump_right.data(), ns * 4, hipMemcpyHostToDevice));
+  CC_HIP(e->d_pred.ensure((size_t)n_samples));
+  PredictArgs A;
+  A.sum = e->d_sum.p;
+  A.tilted = e->use_tilted ? e->d_tilted.p : nullptr;
+  A.normfactor = e->d_nf.p;
+  A.sample_idx = d_idx;
+  A.n_samples = n_samples;
+  A.cols = e->cols;
+  A.nstages = (int)ntrees.size();
+  A.stage_ntrees = d_ntrees.p;
+  A.stage_thr = d_sthr.p;
+  A.feats = haar ? (const void*)dh.p : (const void*)dl.p;
+  A.stump_thr = d_thr.p;
+  A.stump_left = d_left.p;
+  A.stump_right = d_right.p;
+  A.subsets = d_sub.p;
+  A.out = e->d_pred.p;
+  if (haar)
+    hipLaunchKernelGGL(k_predict<true>, dim3((n_samples + 63) / 64), dim3(64), 0, e->stream, A);
+  else
+    hipLaunchKernelGGL(k_predict<false>, dim3((n_samples + 63) / 64), dim3(64), 0, e->stream, A);
+  CC_HIP(hipGetLastError());
+  CC_HIP(hipMemcpyAsync(out, e->d_pred.p, (size_t)n_samples, hipMemcpyDeviceToHost, e->stream));
+  CC_HIP(hipStreamSynchronize(e->stream));
+  return CC_OK;
+}
+
+cc_status cc_eval_last_kernel_ms(cc_evaluator* e, double* ms) {
+  if (!e || !ms) return set_error(CC_ERR_INVALID_ARG, "cc_eval_last_kernel_ms: null argument");
+  *ms = e->last_ms;
+  return CC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// Internal declarations shared by the translation units of libcascadeclassifier_amd.so.
+#pragma once
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/cascadeclassifier_amd.h"
+
+namespace ccamd {
+
+// ---- error plumbing (thread-local message behind cc_last_error) -------------------------------
+cc_status set_error(cc_status code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// ---- minimal XML DOM (the subset cv::FileStorage writes) ---------------------------------------
+struct XmlNode {
+  std::string name;
+  std::string text;  // concatenated character data (entities decoded)
+  std::vector<std::pair<std::string, std::string>> attrs;
+  std::vector<XmlNode> children;
+  const XmlNode* child(const char* n) const {
+    for (const XmlNode& c : children)
+      if (c.name == n) return &c;
+    return nullptr;
+  }
+};
+// Returns false and fills err on malformed input.
+bool xml_parse(const char* text, size_t len, XmlNode& root, std::string& err);
+
+// ---- parsed cascade ------------------------------------------------
+struct HaarFeature {
+  int32_t r[3][4];
+  float w[3];
+  int32_t tilted;
+};
+
+struct Cascade {
+  int feature_type = 0;
+  int win_w = 0, win_h = 0;
+  int max_cat_count = 0, subset_size = 0;
+  int max_nodes_per_tree = 0;
+  bool has_tilted = false;
+  // stages
+  std::vector<int32_t> stage_first, stage_ntrees;
+  std::vector<float> stage_threshold;  // (float)stageThreshold - THRESHOLD_EPS
+  // trees (general form)
+  std::vector<int32_t> tree_first_node, tree_nnodes, tree_first_leaf;
+  std::vector<int32_t> node_left, node_right, node_feature;
+  std::vector<float> node_threshold;
+  std::vector<int32_t> node_subset;  // subset_size words per node
+  std::vector<float> leaves;
+  // stump view (max_nodes_per_tree == 1)
+  std::vector<int32_t> stump_feature;
+  std::vector<float> stump_threshold, stump_left, stump_right;
+  // features
+  std::vector<int32_t> haar_rects;   // [n][3][4]
+  std::vector<float> haar_weights;   // [n][3]
+  std::vector<int32_t> haar_tilted;  // [n]
+  std::vector<int32_t> lbp_rects;    // [n][4]
+  int n_features() const { return feature_type == CC_FEATURE_HAAR ? (int)haar_tilted.size() : (int)(lbp_rects.size() / 4); }
+};
+cc_status cascade_from_xml(const XmlNode& root, Cascade& out);
+
+// ---- pyramid geometry (host) --------------------------------------------------------------------
+struct ScaleGeom {
+  float scale;
+  int w, h, ystep, nx, ny, win_w, win_h;
+};
+void scale_plan(int W0, int H0, int imgw, int imgh, const cc_detect_params& p, std::vector<ScaleGeom>& out);
+
+// Per-axis tap table of the fixed-point bilinear resize: left tap and the 8.8 weight of the right tap
+// (weight of the left tap is 256 - w1). Border samples have w1 = 0.
+struct AxisTaps {
+  std::vector<int32_t> ofs;
+  std::vector<uint16_t> w1;
+};
+void linear_exact_taps(int src, int dst, AxisTaps& t);
+
+void group_rectangles(std::vector<cc_rect>& rects, int group_threshold, double eps);
+
+// ---- catalogs (training side) -------------------------------------------------------------------
+void haar_catalog(int W, int H, int mode, std::vector<HaarFeature>& out);
+void lbp_catalog(int W, int H, std::vector<int32_t>& rects);
+
+}  // namespace ccamd
+
+struct cc_cascade {
+  ccamd::Cascade m;
+};

@@ -1,0 +1,151 @@
+"""Python host mirror of the training-side plugin surface CvFeatureEvaluator / CvHaarEvaluator / CvLBPEvaluator
+(traincascade/lib/include/traincascade_features.h:155-188) on top of the C ABI: same method names, argument meaning
+and error behaviour (CV_Assert failures surface as CascadeError instead of cv::Exception)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+HAAR, LBP, HOG = L.CC_FEATURE_HAAR, L.CC_FEATURE_LBP, L.CC_FEATURE_HOG
+BASIC, CORE, ALL = L.CC_HAAR_BASIC, L.CC_HAAR_CORE, L.CC_HAAR_ALL
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class CvFeatureParams:
+    """CvFeatureParams / CvHaarFeatureParams / CvLBPFeatureParams (haarfeatures.h:31-51, lbpfeatures.h:22-26)."""
+
+    def __init__(self, feature_type=HAAR, mode=BASIC):
+        self.feature_type = feature_type
+        self.mode = mode
+        self.maxCatCount = 256 if feature_type == LBP else 0
+        self.featSize = 1
+
+    @staticmethod
+    def create(feature_type):
+        return CvFeatureParams(feature_type) if feature_type in (HAAR, LBP) else None
+
+
+class CvFeatureEvaluator:
+    def __init__(self, feature_type, device=0):
+        self.feature_type = feature_type
+        self.device = device
+        self._e = C.c_void_p()
+        self.winSize = None
+
+    @staticmethod
+    def create(feature_type, device=0):
+        """features.cpp:91-97: unknown type -> empty Ptr (None here). HOG is outside the accelerated path."""
+        return CvFeatureEvaluator(feature_type, device) if feature_type in (HAAR, LBP) else None
+
+    def init(self, featureParams: CvFeatureParams, maxSampleCount: int, winSize):
+        self._release()
+        w, h = winSize
+        L.check(L.lib().cc_eval_create(self.feature_type, featureParams.mode, int(w), int(h), int(maxSampleCount), self.device,
+                                       C.byref(self._e)))
+        self.winSize = (int(w), int(h))
+        self.featureParams = featureParams
+        self.maxSampleCount = int(maxSampleCount)
+
+    def setImage(self, img, clsLabel: int, idx: int):
+        img = np.ascontiguousarray(img, np.uint8)
+        if img.shape != (self.winSize[1], self.winSize[0]):  # features.cpp:85-86
+            raise L.CascadeError(L.CC_ERR_INVALID_ARG, f"setImage: image {img.shape[::-1]} != winSize {self.winSize}")
+        L.check(L.lib().cc_eval_set_image(self._e, _vp(img), img.shape[1], int(clsLabel), int(idx)))
+
+    def setImages(self, imgs, labels=None, first_idx=0):
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        if imgs.ndim != 3 or imgs.shape[1:] != (self.winSize[1], self.winSize[0]):
+            raise L.CascadeError(L.CC_ERR_INVALID_ARG, "setImages: images do not match winSize")
+        lab = None if labels is None else np.ascontiguousarray(labels, np.uint8)
+        L.check(L.lib().cc_eval_set_images(self._e, _vp(imgs), imgs.shape[0], int(first_idx), _vp(lab)))
+
+    def __call__(self, featureIdx: int, sampleIdx: int) -> float:
+        out = C.c_float(0)
+        L.check(L.lib().cc_eval_calc(self._e, int(featureIdx), int(sampleIdx), C.byref(out)))
+        return out.value
+
+    def calc_batch(self, fi_begin, fi_end, sample_idx=None, n_samples=None) -> np.ndarray:
+        idx = None if sample_idx is None else np.ascontiguousarray(sample_idx, np.int32)
+        ns = len(idx) if idx is not None else (self.maxSampleCount if n_samples is None else n_samples)
+        out = np.empty((fi_end - fi_begin, ns), np.float32)
+        L.check(L.lib().cc_eval_calc_batch(self._e, int(fi_begin), int(fi_end), _vp(idx), ns, _vp(out), 0))
+        return out
+
+    def calc_batch_device(self, fi_begin, fi_end, out_ptr, sample_idx=None, n_samples=None):
+        idx = None if sample_idx is None else np.ascontiguousarray(sample_idx, np.int32)
+        ns = len(idx) if idx is not None else (self.maxSampleCount if n_samples is None else n_samples)
+        L.check(L.lib().cc_eval_calc_batch(self._e, int(fi_begin), int(fi_end), _vp(idx), ns, C.c_void_p(out_ptr), 1))
+
+    def calc_custom_haar(self, feats, normalized=False, sample_idx=None, n_samples=None) -> np.ndarray:
+        """feats: list of (tilted, [(x, y, w, h, weight), ...]) — Feature::calc on stored samples."""
+        arr = (L.HaarFeatureC * len(feats))()
+        for i, (tilted, rects) in enumerate(feats):
+            arr[i].tilted = 1 if tilted else 0
+            for j, r in enumerate(rects):
+                for k in range(4):
+                    arr[i].r[j][k] = int(r[k])
+                arr[i].w[j] = float(r[4])
+        idx = None if sample_idx is None else np.ascontiguousarray(sample_idx, np.int32)
+        ns = len(idx) if idx is not None else (self.maxSampleCount if n_samples is None else n_samples)
+        out = np.empty((len(feats), ns), np.float32)
+        L.check(L.lib().cc_eval_calc_custom_haar(self._e, arr, len(feats), 1 if normalized else 0, _vp(idx), ns, _vp(out)))
+        return out
+
+    def predict_cascade(self, cascade, sample_idx=None, n_samples=None) -> np.ndarray:
+        idx = None if sample_idx is None else np.ascontiguousarray(sample_idx, np.int32)
+        ns = len(idx) if idx is not None else (self.maxSampleCount if n_samples is None else n_samples)
+        out = np.empty(ns, np.uint8)
+        L.check(L.lib().cc_eval_predict_cascade(self._e, cascade._c, _vp(idx), ns, _vp(out)))
+        return out
+
+    def getNumFeatures(self) -> int:
+        return L.lib().cc_eval_num_features(self._e)
+
+    def getMaxCatCount(self) -> int:
+        return L.lib().cc_eval_max_cat_count(self._e)
+
+    def getFeatureSize(self) -> int:
+        return L.lib().cc_eval_feature_size(self._e)
+
+    def getCls(self, si=None):
+        p = L.lib().cc_eval_labels(self._e)
+        a = np.ctypeslib.as_array(p, shape=(self.maxSampleCount,))
+        return a if si is None else float(a[si])
+
+    def feature_geometry(self, fi):
+        rects = np.zeros((3, 4), np.int32)
+        w = np.zeros(3, np.float32)
+        t = C.c_int(0)
+        L.check(L.lib().cc_eval_feature_geometry(self._e, int(fi), _vp(rects), _vp(w), C.byref(t)))
+        return (rects[0].copy(),) if self.feature_type == LBP else (rects, w, t.value)
+
+    def get_sample(self, idx):
+        cols = (self.winSize[0] + 1) * (self.winSize[1] + 1)
+        s = np.empty(cols, np.int32)
+        haar = self.feature_type == HAAR
+        t = np.empty(cols, np.int32) if haar and self.featureParams.mode == ALL else None
+        nf = np.empty(1, np.float32) if haar else None
+        L.check(L.lib().cc_eval_get_sample(self._e, int(idx), _vp(s), _vp(t), _vp(nf)))
+        return s, t, (float(nf[0]) if nf is not None else None)
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_double(0)
+        L.check(L.lib().cc_eval_last_kernel_ms(self._e, C.byref(ms)))
+        return ms.value
+
+    def _release(self):
+        if getattr(self, "_e", None):
+            L.lib().cc_eval_destroy(self._e)
+            self._e = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass

@@ -1,0 +1,239 @@
+/*
+ * cascadeclassifier_amd.h — C ABI of the MI355X-native cascade-classifier hot path.
+ *
+ * Drop-in boundary for ONE path of vladiant/CascadeClassifier: integral-image construction and
+ * Haar / LBP per-window feature evaluation over the sliding-window / scale pyramid, as used by the
+ * detection tool and by CvCascadeBoost stage training. Everything behind these entry points runs as
+ * hand-written HIP kernels on gfx950; there is NO CPU fallback: without a usable HIP device every
+ * compute entry point fails with CC_ERR_NO_DEVICE.
+ *
+ * Each group names the reference interface it replaces (paths relative to the reference repo root).
+ *
+ * Conventions: plain C types; opaque handles; caller-owned buffers; every function returns a
+ * cc_status (0 = OK, < 0 = error) unless documented otherwise; cc_last_error() returns a
+ * thread-local, human-readable message for the last failing call on the calling thread. No
+ * exceptions cross this boundary. Handles are thread-compatible (one thread at a time per handle);
+ * cc_eval_calc* are safe for concurrent callers once cc_eval_set_image(s) has returned, as the
+ * reference's const operator() is (traincascade/lib/src/o_cvcascadeboosttraindata.cpp:586-594).
+ */
+#ifndef CASCADECLASSIFIER_AMD_H_
+#define CASCADECLASSIFIER_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define CC_API __attribute__((visibility("default")))
+#else
+#define CC_API
+#endif
+
+typedef int cc_status;
+enum {
+  CC_OK = 0,
+  CC_ERR_INVALID_ARG = -1,      /* CV_Assert-class failures in the reference (features.cpp:75,85-87) */
+  CC_ERR_NO_DEVICE = -2,        /* HIP runtime / gfx950 device not usable: the product has no CPU path */
+  CC_ERR_HIP = -3,              /* a HIP call failed; message carries hipGetErrorString */
+  CC_ERR_IO = -4,               /* file cannot be opened / read */
+  CC_ERR_PARSE = -5,            /* malformed cascade XML */
+  CC_ERR_UNSUPPORTED = -6,      /* valid input the GPU path does not implement yet (message says which) */
+  CC_ERR_BUFFER_TOO_SMALL = -7, /* output capacity too small; the required size is reported */
+  CC_ERR_OUT_OF_RANGE = -8
+};
+
+CC_API const char* cc_last_error(void);
+CC_API int cc_version(void);
+/* Number of usable HIP devices (0 when there is none or the runtime cannot initialise). */
+CC_API int cc_device_count(void);
+
+typedef struct cc_rect {
+  int32_t x, y, width, height;
+} cc_rect;
+
+/* ============================================================================================
+ * 1. Cascade model (cascade.xml, new format).
+ *    Replaces: cv::CascadeClassifier(const String&) / load() / empty() as called at
+ *    tools/detection/Cpp/main.cpp:42 and tools/detection/Python/detect.py:16; the format is the one
+ *    written by CvCascadeClassifier::save (traincascade/lib/src/cascadeclassifier.cpp:439-456,
+ *    tags traincascade/lib/include/cascadeclassifier.h:27-73).
+ * ============================================================================================ */
+typedef struct cc_cascade cc_cascade;
+
+enum { CC_FEATURE_HAAR = 0, CC_FEATURE_LBP = 1, CC_FEATURE_HOG = 2 };
+
+typedef struct cc_cascade_info {
+  int32_t feature_type; /* CC_FEATURE_* */
+  int32_t win_w, win_h;
+  int32_t n_stages, n_weak, n_nodes, n_leaves, n_features;
+  int32_t max_cat_count, subset_size;
+  int32_t max_nodes_per_tree; /* 1 => stump cascade */
+  int32_t has_tilted;
+} cc_cascade_info;
+
+CC_API cc_status cc_cascade_load_xml(const char* path, cc_cascade** out);
+CC_API cc_status cc_cascade_load_xml_mem(const char* text, size_t len, cc_cascade** out);
+CC_API void cc_cascade_destroy(cc_cascade* c);
+CC_API cc_status cc_cascade_info_get(const cc_cascade* c, cc_cascade_info* info);
+/* Flat views of the parsed model (for inspection / parity tests). Arrays are owned by the cascade. */
+CC_API cc_status cc_cascade_stages(const cc_cascade* c, const int32_t** first_weak, const int32_t** n_weak,
+                                   const float** threshold /* (float)stageThreshold - 1e-5f */);
+/* Stump view (valid when max_nodes_per_tree == 1): per weak classifier feature index, threshold, leaf values and
+ * (LBP) subset_size int32 words of category mask. */
+CC_API cc_status cc_cascade_stumps(const cc_cascade* c, const int32_t** feature_idx, const float** threshold,
+                                   const float** left, const float** right, const int32_t** subsets);
+/* Haar: rects as int32[n_features][3][4] (x y w h), weights float[n_features][3], tilted int32[n_features].
+ * LBP:  rects as int32[n_features][4]; weights / tilted are NULL. */
+CC_API cc_status cc_cascade_features(const cc_cascade* c, const int32_t** rects, const float** weights,
+                                     const int32_t** tilted);
+
+/* ============================================================================================
+ * 2. Detector.
+ *    Replaces: cv::CascadeClassifier::detectMultiScale(gray, objects, scaleFactor, minNeighbors, flags,
+ *    minSize, maxSize) as called at tools/detection/Cpp/main.cpp:45 (gray, objects, 4, 50) and
+ *    tools/detection/Python/detect.py:22; internally cv::resize(INTER_LINEAR_EXACT), cv::integral and
+ *    cv::groupRectangles (OpenCV 4.6.0, external/CMakeLists.txt:11).
+ * ============================================================================================ */
+typedef struct cc_detector cc_detector;
+
+typedef struct cc_detect_params {
+  double scale_factor;   /* > 1 */
+  int32_t min_neighbors; /* groupRectangles threshold; <= 0 returns ungrouped candidates */
+  int32_t min_w, min_h;  /* 0 = no limit */
+  int32_t max_w, max_h;  /* 0 = image size */
+} cc_detect_params;
+
+/* device: HIP device ordinal. max_batch: frames processed per pass (workspace is sized for it). */
+CC_API cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_detector** out);
+CC_API void cc_detector_destroy(cc_detector* d);
+/* Use the caller's HIP stream (hipStream_t) for all work of this detector; NULL = detector's own stream. */
+CC_API cc_status cc_detector_set_stream(cc_detector* d, void* hip_stream);
+
+/* One frame, host memory. out receives at most cap rectangles; *n = number found (if *n > cap the call returns
+ * CC_ERR_BUFFER_TOO_SMALL and fills the first cap). Rectangle order: class order of cv::groupRectangles for
+ * candidates sorted (scale, y, x), i.e. OpenCV's single-threaded order. */
+CC_API cc_status cc_detect_multiscale(cc_detector* d, const uint8_t* gray, int width, int height, size_t row_stride,
+                                      const cc_detect_params* p, cc_rect* out, int cap, int* n);
+
+/* Batch of equally sized frames. frames points to HOST memory (on_device = 0) or to DEVICE memory of the detector's
+ * device (on_device = 1; e.g. a torch tensor's data_ptr): frame f starts at frames + f * frame_stride.
+ * Output: rectangles of frame f are out[offsets[f] .. offsets[f+1]); offsets has n_frames + 1 entries. */
+CC_API cc_status cc_detect_batch(cc_detector* d, const uint8_t* frames, int on_device, int n_frames, int width,
+                                 int height, size_t row_stride, size_t frame_stride, const cc_detect_params* p,
+                                 cc_rect* out, int cap, int32_t* offsets);
+
+/* Same, but only the device pipeline (pyramid, integrals, cascade evaluation, skip-rule filter): candidates stay on
+ * the device, nothing is copied back or grouped. For benchmarking the kernels. */
+CC_API cc_status cc_detect_batch_device_only(cc_detector* d, const uint8_t* frames, int on_device, int n_frames,
+                                             int width, int height, size_t row_stride, size_t frame_stride,
+                                             const cc_detect_params* p);
+
+/* Ungrouped candidates of one frame, as int32[7] = {scale_idx, gx, gy, x, y, w, h}, sorted (scale, gy, gx). */
+CC_API cc_status cc_detect_raw(cc_detector* d, const uint8_t* gray, int width, int height, size_t row_stride,
+                               const cc_detect_params* p, int32_t* cand, int cap, int* n);
+
+/* Parity instrumentation: per grid window result of runAt for one frame, all scales concatenated scale-major,
+ * row-major [gy][gx]: codes: 1 pass, -k rejected at stage k (0 = stage 0), -1 window rejected before stage 0
+ * (variance test); sums: stage accumulator (double) at exit; visited: 1 when OpenCV's scan loop visits the window
+ * (stage-0 skip rule). Any of the three may be NULL. n_windows = capacity / total count. */
+CC_API cc_status cc_detect_debug_windows(cc_detector* d, const uint8_t* gray, int width, int height, size_t row_stride,
+                                         const cc_detect_params* p, int32_t* codes, double* sums, uint8_t* visited,
+                                         int64_t cap, int64_t* n_windows);
+
+/* Scale pyramid geometry for an image size (host computation only; no device needed). */
+typedef struct cc_scale_info {
+  float scale;
+  int32_t width, height; /* resized image */
+  int32_t ystep;
+  int32_t nx, ny;        /* grid windows enumerated along x / y */
+  int32_t win_w, win_h;  /* emitted rectangle size */
+} cc_scale_info;
+CC_API cc_status cc_scale_plan(int win_w, int win_h, int width, int height, const cc_detect_params* p,
+                               cc_scale_info* out, int cap, int* n);
+
+/* Per-kernel device time accumulated since the last reset, measured with HIP events on the detector's stream.
+ * Profiling is off by default (no events are recorded). */
+typedef struct cc_detector_timings {
+  double resize_ms, integral_ms, eval_ms, finalize_ms;
+  int64_t resize_launches, integral_launches, eval_launches, finalize_launches;
+  int64_t frames;         /* frames processed */
+  int64_t grid_windows;   /* grid windows evaluated */
+  int64_t integral_elems; /* integral entries per channel produced */
+} cc_detector_timings;
+CC_API cc_status cc_detector_set_profiling(cc_detector* d, int enabled);
+CC_API cc_status cc_detector_get_timings(cc_detector* d, cc_detector_timings* t, int reset);
+
+/* ============================================================================================
+ * 3. Building blocks exposed for parity tests and roofline measurement (all run on the device).
+ *    Replace: cv::integral (traincascade/lib/src/haarfeatures.cpp:109,112, lbpfeatures.cpp:27),
+ *    cv::resize INTER_LINEAR_EXACT (traincascade/lib/src/imagestorage.cpp:86,117), cv::groupRectangles.
+ * ============================================================================================ */
+/* sum / sqsum / tilted: (height+1) x (width+1) int32, densely packed; sqsum is the detector's CV_32S variant
+ * (wrap-around accumulation); any output may be NULL. */
+CC_API cc_status cc_integral_u8(int device, const uint8_t* img, int width, int height, size_t row_stride, int32_t* sum,
+                                int32_t* sqsum, int32_t* tilted);
+CC_API cc_status cc_resize_linear_exact_u8(int device, const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst,
+                                           int dw, int dh, size_t dstride);
+/* Host-side (tiny, serial in the reference too): cv::groupRectangles(rects, group_threshold, eps). */
+CC_API cc_status cc_group_rectangles(const cc_rect* rects, int n, int group_threshold, double eps, cc_rect* out, int cap,
+                                     int* n_out);
+
+/* ============================================================================================
+ * 4. Training-side feature evaluator.
+ *    Replaces: CvFeatureEvaluator / CvHaarEvaluator / CvLBPEvaluator
+ *    (traincascade/lib/include/traincascade_features.h:155-188, haarfeatures.h:61-122, lbpfeatures.h:37-83):
+ *    create+init  -> cc_eval_create           (features.cpp:72-81,91-97; haarfeatures.cpp:89-98; lbpfeatures.cpp:15-20)
+ *    setImage     -> cc_eval_set_image(s)     (features.cpp:83-89; haarfeatures.cpp:100-114; lbpfeatures.cpp:22-28)
+ *    operator()   -> cc_eval_calc / cc_eval_calc_batch (haarfeatures.h:108-122; lbpfeatures.h:44-45,70-83)
+ *    getNumFeatures/getMaxCatCount/getFeatureSize/getCls -> cc_eval_* getters
+ *    writeFeatures needs only the geometry -> cc_eval_feature_geometry (haarfeatures.cpp:311-320, lbpfeatures.cpp:65-68)
+ *    bulk consumer CvCascadeBoostTrainData::precalculate (o_cvcascadeboosttraindata.cpp:490-596) -> cc_eval_calc_batch.
+ * ============================================================================================ */
+typedef struct cc_evaluator cc_evaluator;
+enum { CC_HAAR_BASIC = 0, CC_HAAR_CORE = 1, CC_HAAR_ALL = 2 };
+
+CC_API cc_status cc_eval_create(int feature_type, int haar_mode, int win_w, int win_h, int max_samples, int device,
+                                cc_evaluator** out);
+CC_API void cc_eval_destroy(cc_evaluator* e);
+CC_API int cc_eval_num_features(const cc_evaluator* e);
+CC_API int cc_eval_max_cat_count(const cc_evaluator* e); /* 0 Haar, 256 LBP */
+CC_API int cc_eval_feature_size(const cc_evaluator* e);  /* 1 */
+/* Haar: rects int32[3][4], weights float[3], *tilted; LBP: rects[0] = one cell (x y w h), weights/tilted untouched. */
+CC_API cc_status cc_eval_feature_geometry(const cc_evaluator* e, int fi, int32_t* rects, float* weights, int* tilted);
+/* img: win_h rows of win_w bytes, row_stride bytes apart. idx < max_samples. */
+CC_API cc_status cc_eval_set_image(cc_evaluator* e, const uint8_t* img, size_t row_stride, uint8_t cls_label, int idx);
+/* n images of win_w x win_h, densely packed, stored at idx first_idx..first_idx+n-1; labels may be NULL (labels kept). */
+CC_API cc_status cc_eval_set_images(cc_evaluator* e, const uint8_t* imgs, int n, int first_idx, const uint8_t* labels);
+/* Host array of max_samples floats (the reference's `cls` Mat; o_cvcascadeboosttraindata.cpp:238-239 wraps it). */
+CC_API const float* cc_eval_labels(const cc_evaluator* e);
+/* Scalar operator()(featureIdx, sampleIdx): one device evaluation (slow; prefer the batch form). */
+CC_API cc_status cc_eval_calc(cc_evaluator* e, int fi, int si, float* out);
+/* out[(fi - fi_begin) * n_samples + s] = evaluator(fi, sample_idx ? sample_idx[s] : s); out is HOST memory unless
+ * out_on_device != 0 (then it is memory of the evaluator's device). */
+CC_API cc_status cc_eval_calc_batch(cc_evaluator* e, int fi_begin, int fi_end, const int32_t* sample_idx, int n_samples,
+                                    float* out, int out_on_device);
+/* Feature::calc (un-normalised) of caller-supplied Haar features on stored samples: the shape of the reference KATs
+ * test_features.cpp:462-560. feats: n x {tilted, rects[3][4], weights[3]} as below. */
+typedef struct cc_haar_feature {
+  int32_t tilted;
+  int32_t r[3][4];
+  float w[3];
+} cc_haar_feature;
+CC_API cc_status cc_eval_calc_custom_haar(cc_evaluator* e, const cc_haar_feature* feats, int n_feats, int normalized,
+                                          const int32_t* sample_idx, int n_samples, float* out);
+/* Cached per-sample data copied back for parity tests: sum / tilted are (win_w+1)*(win_h+1) int32. */
+CC_API cc_status cc_eval_get_sample(cc_evaluator* e, int idx, int32_t* sum, int32_t* tilted, float* normfactor);
+/* Training-side cascade predict (CvCascadeClassifier::predict, cascadeclassifier.cpp:297-306 ->
+ * boost.cpp:461-477 -> o_cvcascadeboosttree.cpp:16-39) of a stump cascade over stored samples:
+ * out[s] = 1 if every stage passes else 0. Feature indices of `c` index the cascade's own <features> list. */
+CC_API cc_status cc_eval_predict_cascade(cc_evaluator* e, const cc_cascade* c, const int32_t* sample_idx, int n_samples,
+                                         uint8_t* out);
+CC_API cc_status cc_eval_last_kernel_ms(cc_evaluator* e, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASCADECLASSIFIER_AMD_H_ */

@@ -1,0 +1,177 @@
+"""GPU parity tests of the detection path: every stage of the HIP pipeline is compared with the CPU oracle through the
+C ABI on seeded inputs. Integer / index work (resize, integrals, LBP codes, result codes, visited flags, rectangles) is
+BIT-EXACT; Haar stage sums are compared exactly too (tolerance 0.0: the kernels reproduce the CPU operation order with
+FMA contraction off, float feature values and a double accumulator), see HAAR_SUM_TOL."""
+import os
+
+import numpy as np
+import pytest
+
+import cascadeclassifier_amd as cc
+from cascadeclassifier_amd import _lib as L
+from cascadeclassifier_amd import detector as det
+from oracle import oracle as orc
+from tests.util import frame_natural, frame_uniform
+
+pytestmark = pytest.mark.gpu
+
+HAAR_SUM_TOL = 0.0  # absolute tolerance on Haar stage sums (north_star allows a stated tolerance; we hold exact)
+
+
+def _faces(img, seed, ks=(1.0, 1.7, 2.6, 4.0)):
+    tm = np.load(os.path.join(os.path.dirname(__file__), "..", "data", "face_template_24x24.npy"))
+    rng = np.random.default_rng(seed)
+    out = img.copy()
+    h, w = out.shape
+    for k in ks:
+        s = int(24 * k)
+        if s >= min(h, w):
+            continue
+        u = orc.resize_linear_exact(tm, s, s)
+        y, x = int(rng.integers(0, h - s)), int(rng.integers(0, w - s))
+        out[y:y + s, x:x + s] = u
+    return out
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(640, 480, 582, 436), (640, 480, 160, 120), (1920, 1080, 1745, 982), (101, 57, 33, 19),
+                                         (64, 64, 64, 64), (50, 40, 49, 39), (333, 127, 7, 3), (24, 24, 1, 1)])
+def test_resize_bit_exact(sw, sh, dw, dh):
+    img = frame_uniform(sw, sh, 11)
+    assert (det.resize_linear_exact(img, dw, dh) == orc.resize_linear_exact(img, dw, dh)).all()
+
+
+@pytest.mark.parametrize("w,h", [(24, 24), (25, 31), (640, 480), (1920, 1080), (257, 3), (3, 257), (1000, 1)])
+def test_integral_bit_exact(w, h):
+    img = frame_uniform(w, h, 5)
+    if w * h > 100000:
+        img[: h // 2] = 255  # force the squared sum past 2^32
+    g = det.integral(img, sqsum=True)
+    o = orc.integral(img, sqsum_i32=True)
+    assert (g["sum"] == o["sum"]).all()
+    assert (g["sqsum"] == o["sqsum_i32"]).all()
+
+
+def test_integral_tilted_bit_exact():
+    img = frame_uniform(61, 47, 9)
+    g = det.integral(img, tilted=True)
+    assert (g["tilted"] == orc.integral(img, tilted=True)["tilted"]).all()
+
+
+def _compare_windows(xml, img, sf, haar, min_size=None, max_size=None):
+    o = orc.load_cascade_xml(xml)
+    p = cc.CascadeClassifier(xml)
+    ref = orc.detect_raw(o, img, sf, min_size or (0, 0), max_size or (0, 0), nthreads=8, full=True)
+    codes, sums, vis = p.debug_windows(img, sf, min_size, max_size)
+    assert len(codes) == ref.n_grid_windows
+    assert (codes == ref.codes).all(), f"{(codes != ref.codes).sum()} window results differ"
+    if haar:
+        assert np.max(np.abs(sums - ref.sums), initial=0.0) <= HAAR_SUM_TOL
+    else:
+        assert (sums == ref.sums).all()
+    assert (vis == ref.visited).all()
+    raw = p.detect_raw(img, sf, min_size, max_size)
+    assert raw.shape == ref.candidates.shape and (raw == ref.candidates).all()
+    return p, o, ref
+
+
+@pytest.mark.parametrize("w,h,sf,seed", [(640, 480, 1.1, 1), (640, 480, 4.0, 2), (333, 127, 1.3, 3), (97, 211, 1.1, 4)])
+def test_lbp_windows_bit_exact(lbp_xml, w, h, sf, seed):
+    _compare_windows(lbp_xml, frame_natural(w, h, seed), sf, haar=False)
+
+
+@pytest.mark.parametrize("w,h,sf,seed", [(640, 480, 1.1, 1), (640, 480, 4.0, 2), (333, 127, 1.3, 3), (97, 211, 1.1, 4)])
+def test_haar_windows_exact(haar_xml, w, h, sf, seed):
+    img = _faces(frame_natural(w, h, seed), seed)
+    _compare_windows(haar_xml, img, sf, haar=True)
+
+
+def test_haar_uniform_noise_and_flat_image(haar_xml):
+    _compare_windows(haar_xml, frame_uniform(320, 240, 7), 1.1, haar=True)
+    flat = np.full((100, 120), 77, np.uint8)  # zero variance: every window fails the variance test, no skip
+    p, o, ref = _compare_windows(haar_xml, flat, 1.1, haar=True)
+    assert (ref.codes == -1).all() and len(ref.candidates) == 0
+    sat = np.full((400, 400), 255, np.uint8)  # squared-sum integral wraps past 2^32
+    sat[::7, ::5] = 0
+    _compare_windows(haar_xml, sat, 1.2, haar=True)
+
+
+def test_min_max_size_filters(haar_xml, lbp_xml):
+    img = _faces(frame_natural(480, 360, 21), 21)
+    _compare_windows(haar_xml, img, 1.1, True, min_size=(40, 40))
+    _compare_windows(haar_xml, img, 1.1, True, max_size=(60, 60))
+    _compare_windows(lbp_xml, img, 1.1, False, min_size=(50, 50), max_size=(50, 50))
+
+
+@pytest.mark.parametrize("which", ["haar", "lbp"])
+def test_detect_multiscale_rectangles_identical(haar_xml, lbp_xml, which):
+    xml = haar_xml if which == "haar" else lbp_xml
+    o = orc.load_cascade_xml(xml)
+    p = cc.CascadeClassifier(xml)
+    for seed, (w, h) in enumerate([(640, 480), (800, 450), (320, 200)]):
+        img = _faces(frame_natural(w, h, 30 + seed), seed)
+        for sf, mn in ((1.1, 3), (1.1, 0), (1.25, 2), (4.0, 50), (4.0, 1)):  # (4, 50) = tools/detection/Cpp/main.cpp:45
+            a = p.detectMultiScale(img, sf, mn)
+            b = orc.detect_multiscale(o, img, sf, mn, nthreads=8)
+            assert a.shape == b.shape and (a == b).all(), (which, seed, sf, mn)
+
+
+def test_tiny_and_degenerate_images(haar_xml):
+    p = cc.CascadeClassifier(haar_xml)
+    o = orc.load_cascade_xml(haar_xml)
+    for (w, h) in [(23, 100), (100, 23), (24, 24), (25, 24), (24, 25), (1, 1)]:
+        img = frame_natural(max(w, 2), max(h, 2), 3)[:h, :w]
+        a = p.detectMultiScale(img, 1.1, 0)
+        b = orc.detect_multiscale(o, img, 1.1, 0)
+        assert a.shape == b.shape and (a == b).all()
+    with pytest.raises(cc.CascadeError):
+        p.detectMultiScale(frame_natural(64, 64, 1), 1.0, 3)  # scaleFactor must be > 1
+
+
+def test_batch_matches_single_frames(haar_xml):
+    frames = np.stack([_faces(frame_natural(400, 300, 50 + i), i) for i in range(5)])
+    o = orc.load_cascade_xml(haar_xml)
+    for mb in (1, 2, 8):
+        p = cc.CascadeClassifier(haar_xml, max_batch=mb)
+        got = p.detect_batch(frames, 1.1, 3)
+        for i in range(5):
+            b = orc.detect_multiscale(o, frames[i], 1.1, 3, nthreads=8)
+            assert got[i].shape == b.shape and (got[i] == b).all()
+
+
+def test_batch_from_device_memory(lbp_xml):
+    import torch
+    frames = np.stack([frame_natural(320, 240, 70 + i) for i in range(3)])
+    t = torch.from_numpy(frames).cuda()
+    p = cc.CascadeClassifier(lbp_xml, max_batch=4)
+    got = p.detect_batch(None, 1.1, 3, device_ptr=t.data_ptr(), shape=tuple(frames.shape))
+    o = orc.load_cascade_xml(lbp_xml)
+    for i in range(3):
+        b = orc.detect_multiscale(o, frames[i], 1.1, 3, nthreads=8)
+        assert got[i].shape == b.shape and (got[i] == b).all()
+
+
+def test_full_hd_properties(haar_xml):
+    """BASELINE size (1920x1080, 40 scales, 4 514 050 windows): full oracle comparison of the candidate set plus
+    size-independent properties (window census, visited count, determinism)."""
+    img = _faces(frame_natural(1920, 1080, 0), 0, ks=(1.0, 2.0, 5.0, 9.0))
+    o = orc.load_cascade_xml(haar_xml)
+    p = cc.CascadeClassifier(haar_xml)
+    codes, sums, vis = p.debug_windows(img, 1.1)
+    assert len(codes) == 4514050
+    ref = orc.detect_raw(o, img, 1.1, nthreads=16, full=True)
+    assert (codes == ref.codes).all() and (vis == ref.visited).all()
+    assert np.max(np.abs(sums - ref.sums)) <= HAAR_SUM_TOL
+    assert int(vis.sum()) == ref.n_visited_windows
+    raw1 = p.detect_raw(img, 1.1)
+    raw2 = p.detect_raw(img, 1.1)
+    assert (raw1 == raw2).all() and (raw1 == ref.candidates).all()
+    a = p.detectMultiScale(img, 1.1, 3)
+    assert (a == orc.detect_multiscale(o, img, 1.1, 3, nthreads=16)).all() and len(a) >= 3
+
+
+def test_profiling_counters(lbp_xml):
+    p = cc.CascadeClassifier(lbp_xml)
+    p.set_profiling(True)
+    p.detectMultiScale(frame_natural(640, 480, 1), 1.1, 3)
+    t = p.timings(reset=True)
+    assert t["frames"] == 1 and t["grid_windows"] == 585373 and t["eval_launches"] == 1 and t["eval_ms"] > 0

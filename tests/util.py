@@ -45,3 +45,16 @@ def paste_patches(img, patches, seed):
         x = int(rng.integers(0, w - pw))
         out[y:y + ph, x:x + pw] = p
     return out
+
+
+def upscale(patch, size):
+    """Plain numpy bilinear up/down-scale of a square patch to size x size (input synthesis only)."""
+    n = patch.shape[0]
+    c = (np.arange(size) + 0.5) * (n / size) - 0.5
+    i0 = np.clip(np.floor(c).astype(int), 0, n - 1)
+    i1 = np.clip(i0 + 1, 0, n - 1)
+    f = np.clip(c - i0, 0.0, 1.0)
+    p = patch.astype(np.float64)
+    rows = p[i0] * (1 - f)[:, None] + p[i1] * f[:, None]
+    out = rows[:, i0] * (1 - f)[None, :] + rows[:, i1] * f[None, :]
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
