@@ -112,6 +112,25 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One process must hold ONE HIP runtime: PyTorch-ROCm wheels bundle their own libamdhip64.so.7, and a second copy
+    (the system one our DT_NEEDED would pick) cannot open the GPU once the first has. Pre-load torch's copy (same
+    SONAME) when a torch wheel is installed, so this library and a later `import torch` share it. Without torch the
+    system runtime under /opt/rocm is used. CCAMD_HIP_RUNTIME=system forces the latter."""
+    if os.environ.get("CCAMD_HIP_RUNTIME", "torch") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -119,6 +138,7 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
                 "or make -C cascadeclassifier_amd/csrc). There is no CPU fallback.")
+        _share_torch_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
