@@ -39,6 +39,18 @@ def make_frames(n, w, h, seed0):
     return frames
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,7 +170,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         from oracle import oracle as orc
         o = orc.load_cascade_xml(args.cascade)
-        cores = len(os.sched_getaffinity(0))
+        cores = usable_cores()
         nfr = min(args.cpu_frames, B)
         orc.detect_multiscale(o, frames_host[0][:270, :480], args.scale_factor, args.min_neighbors, nthreads=cores)  # warm-up
         t0 = time.perf_counter()

@@ -30,6 +30,25 @@ namespace ccamd {
                                            __FILE__, __LINE__);                                              \
   } while (0)
 
+// Read-only tables (cascade, scale descriptors, tile list) are written by the host before the launch and never by a
+// kernel: addressing them through the constant address space lets wave-uniform reads become scalar loads (s_load).
+#define CC_CONST __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const T CC_CONST* as_const_table(const T* p) {
+  return (const T CC_CONST*)p;
+}
+// Copies one table record (a multiple of 4 bytes) out of the constant address space, dword by dword.
+template <class T>
+__device__ __forceinline__ T load_record(const T CC_CONST* p) {
+  static_assert(sizeof(T) % 4 == 0, "table records are dword multiples");
+  T out;
+  const int CC_CONST* w = (const int CC_CONST*)p;
+  int* o = reinterpret_cast<int*>(&out);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) o[i] = w[i];
+  return out;
+}
+
 constexpr int TILE_X = 64;   // window origins per tile row = one wavefront = one rej0 mask word
 constexpr int TILE_Y = 16;   // window origin rows per tile
 constexpr int WIN_PER_THREAD = 4;  // 4 waves x 4 rows
@@ -244,8 +263,16 @@ __global__ void k_tilted_from_sum(const int32_t* __restrict__ sum, int pitchI, i
 // K4: cascade evaluation. Block = 256 threads = 4 wavefronts = one tile of 64 x 16 window origins of one scale.
 // The tile of the `sum` integral the windows touch is staged once into LDS (for STEP 2 with even and odd columns
 // in separate planes, so that a wavefront's stride-2 corner reads are bank-conflict free); every rectangle corner
-// is then an LDS read. Lane = window column, each thread owns 4 window rows. Stage loop with early exit:
-// a wavefront leaves as soon as none of its 256 windows is alive.
+// is then an LDS read. The cascade's early exit is handled by COMPACTION instead of divergence:
+//   phase D (dense)  : lane = window column, 4 window rows per thread: variance test + stage 0 for all 1024 windows;
+//                      wave ballots give the stage-0 rejection mask words; survivors are appended to an LDS queue
+//                      (wave ballot + one LDS atomic per wave);
+//   phase T (thread) : stage by stage, one thread per queued window (full wavefronts), survivors re-queued into the
+//                      other LDS queue buffer;
+//   phase W (wave)   : once fewer than `wave_below` windows are left in the block, one wavefront per window: the 64
+//                      lanes split the stage's stumps and reduce their votes. Only used when the stage sums of the
+//                      cascade are provably order-independent (exact in double, checked on the host at load time),
+//                      so the reduction is bit-identical to the sequential CPU accumulation.
 // ------------------------------------------------------------------------------------------------
 template <int STEP>
 struct TileGeom {
@@ -263,10 +290,17 @@ struct TileGeom {
   __host__ __device__ int words() const { return rows * row_stride; }
 };
 
+constexpr int TILE_WINDOWS = TILE_X * TILE_Y;  // 1024
+constexpr int MAX_STAGES = 64;                 // per-stage queue counters live in LDS
+// LDS bytes per block: integral tile + vnf[1024] + 2 queues of u16[1024] + int counters[MAX_STAGES]
+__host__ __device__ inline size_t eval_lds_bytes(int tile_words) {
+  return (size_t)tile_words * 4 + TILE_WINDOWS * 4 + 2 * TILE_WINDOWS * 2 + MAX_STAGES * 4;
+}
+
 template <int STEP>
 __device__ __forceinline__ void stage_tile(int32_t* lds, const TileGeom<STEP>& G, const int32_t* __restrict__ sum,
                                            const ScaleDev& S, int x0, int y0) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int r = wave; r < G.rows; r += 4) {
     const int gr = y0 + r;
     const int32_t* src = sum + (size_t)gr * S.pitchI;
@@ -287,10 +321,12 @@ struct EvalArgs {
   const int4* tiles;  // {scale, tx, ty, 0}
   int W0, H0;
   int nstages;
+  const int* stage_first;  // first stump of each stage
   const int* stage_ntrees;
   const float* stage_thr;
   const void* stumps1;  // stump tables in STEP-1 / STEP-2 tile coordinates
   const void* stumps2;
+  int wave_below;       // switch to one wavefront per window when fewer windows than this are queued (0 = never)
   unsigned long long* masks;
   size_t mask_frame_words;
   CandRaw* cands;
@@ -300,196 +336,197 @@ struct EvalArgs {
   double* dbg_sums;
 };
 
-template <int STEP>
-__device__ __forceinline__ void eval_haar_tile(const EvalArgs& A, int32_t* lds, const int4 T, const ScaleDev& S) {
-  const TileGeom<STEP> G(A.W0, A.H0);
-  const int frame = blockIdx.y;
-  const int32_t* sum = A.integ + ((size_t)frame * A.nchan + 0) * A.int_frame_elems + S.int_ofs;
-  const unsigned* sq = reinterpret_cast<const unsigned*>(A.integ + ((size_t)frame * A.nchan + 1) * A.int_frame_elems + S.int_ofs);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gx = T.y * TILE_X + lane;
-  const int x0 = T.y * TILE_X * STEP, y0 = T.z * TILE_Y * STEP;
-  stage_tile<STEP>(lds, G, sum, S, x0, y0);
-  __syncthreads();
-
-  // per-window state
-  int base[WIN_PER_THREAD];
-  float vnf[WIN_PER_THREAD];
-  bool alive[WIN_PER_THREAD];
-  int code[WIN_PER_THREAD];
-  double last[WIN_PER_THREAD];
-  const int nrx = A.W0 - 2, nry = A.H0 - 2;
-  const double area = (double)(nrx * nry);
-  const int n0 = G.at(1, 1), n1 = G.at(1, 1 + nrx), n2 = G.at(1 + nry, 1), n3 = G.at(1 + nry, 1 + nrx);
-#pragma unroll
-  for (int k = 0; k < WIN_PER_THREAD; k++) {
-    const int ly = wave * WIN_PER_THREAD + k;  // window row inside the tile
-    const int gy = T.z * TILE_Y + ly;
-    base[k] = (ly * STEP) * G.row_stride + (STEP == 2 ? lane : lane);
-    const bool in_grid = gx < S.nx && gy < S.ny;
-    alive[k] = false;
-    code[k] = -1;
-    last[k] = 0.0;
-    vnf[k] = 1.f;
-    if (in_grid) {
-      const int x = gx * STEP, y = gy * STEP;
-      const int valsum = lds[base[k] + n0] - lds[base[k] + n1] - lds[base[k] + n2] + lds[base[k] + n3];
-      const size_t q0 = (size_t)(y + 1) * S.pitchI + (x + 1);
-      const unsigned valsq = sq[q0] - sq[q0 + nrx] - sq[q0 + (size_t)nry * S.pitchI] + sq[q0 + (size_t)nry * S.pitchI + nrx];
-      double nf = area * (double)valsq - (double)valsum * (double)valsum;
-      if (nf > 0.) {
-        nf = sqrt(nf);
-        vnf[k] = (float)(1. / nf);
-        alive[k] = area * (double)vnf[k] < 1e-1;
-      }
-    }
+// ---- one weak classifier on one window; `b` = LDS address of the window's tile base ----------------------------
+__device__ __forceinline__ double stump_vote(const int32_t* b, const HaarStumpDev CC_CONST* spp, float vnf) {
+  const HaarStumpDev sp = load_record(spp);
+  const int r0 = b[sp.ofs[0][0]] - b[sp.ofs[0][1]] - b[sp.ofs[0][2]] + b[sp.ofs[0][3]];
+  const int r1 = b[sp.ofs[1][0]] - b[sp.ofs[1][1]] - b[sp.ofs[1][2]] + b[sp.ofs[1][3]];
+  float v = sp.w[0] * (float)r0 + sp.w[1] * (float)r1;
+  if (sp.nrect == 3) {
+    const int r2 = b[sp.ofs[2][0]] - b[sp.ofs[2][1]] - b[sp.ofs[2][2]] + b[sp.ofs[2][3]];
+    v += sp.w[2] * (float)r2;
   }
-
-  const HaarStumpDev* __restrict__ stumps = reinterpret_cast<const HaarStumpDev*>(STEP == 2 ? A.stumps2 : A.stumps1);
-  int si = 0;
-  bool rej0[WIN_PER_THREAD] = {false, false, false, false};
-  for (int st = 0; st < A.nstages; st++) {
-    const bool any_mine = alive[0] | alive[1] | alive[2] | alive[3];
-    if (!__any(any_mine)) break;
-    const int nt = A.stage_ntrees[st];
-    double acc[WIN_PER_THREAD] = {0., 0., 0., 0.};
-    for (int i = 0; i < nt; i++, si++) {
-      const HaarStumpDev sp = stumps[si];
-      float v[WIN_PER_THREAD];
-#pragma unroll
-      for (int k = 0; k < WIN_PER_THREAD; k++) {
-        const int32_t* b = lds + base[k];
-        const int r0 = b[sp.ofs[0][0]] - b[sp.ofs[0][1]] - b[sp.ofs[0][2]] + b[sp.ofs[0][3]];
-        const int r1 = b[sp.ofs[1][0]] - b[sp.ofs[1][1]] - b[sp.ofs[1][2]] + b[sp.ofs[1][3]];
-        v[k] = sp.w[0] * (float)r0 + sp.w[1] * (float)r1;
-      }
-      if (sp.nrect == 3) {
-#pragma unroll
-        for (int k = 0; k < WIN_PER_THREAD; k++) {
-          const int32_t* b = lds + base[k];
-          const int r2 = b[sp.ofs[2][0]] - b[sp.ofs[2][1]] - b[sp.ofs[2][2]] + b[sp.ofs[2][3]];
-          v[k] += sp.w[2] * (float)r2;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < WIN_PER_THREAD; k++) {
-        const float val = v[k] * vnf[k];
-        acc[k] += (double)(val < sp.thr ? sp.left : sp.right);
-      }
-    }
-    const double thr = (double)A.stage_thr[st];
-#pragma unroll
-    for (int k = 0; k < WIN_PER_THREAD; k++) {
-      if (alive[k]) {
-        last[k] = acc[k];
-        if (acc[k] < thr) {
-          alive[k] = false;
-          code[k] = -st;
-          if (st == 0) rej0[k] = true;
-        }
-      }
-    }
-  }
-
-#pragma unroll
-  for (int k = 0; k < WIN_PER_THREAD; k++) {
-    const int gy = T.z * TILE_Y + wave * WIN_PER_THREAD + k;
-    const unsigned long long m = __ballot(rej0[k]);
-    if (gy < S.ny) {
-      if (lane == 0) A.masks[(size_t)frame * A.mask_frame_words + S.mask_ofs + (size_t)gy * S.nxw + T.y] = m;
-      if (gx < S.nx) {
-        if (alive[k]) {
-          code[k] = 1;
-          const int slot = atomicAdd(A.cand_count, 1);
-          if (slot < A.cand_cap) A.cands[slot] = CandRaw{frame, T.x, gx, gy};
-        }
-        if (A.dbg_codes && frame == 0) {
-          const size_t o = (size_t)S.win_ofs + (size_t)gy * S.nx + gx;
-          A.dbg_codes[o] = code[k];
-          if (A.dbg_sums) A.dbg_sums[o] = last[k];
-        }
-      }
-    }
-  }
+  v *= vnf;
+  return (double)(v < sp.thr ? sp.left : sp.right);
 }
 
-template <int STEP>
-__device__ __forceinline__ void eval_lbp_tile(const EvalArgs& A, int32_t* lds, const int4 T, const ScaleDev& S) {
+__device__ __forceinline__ double stump_vote(const int32_t* b, const LbpStumpDev CC_CONST* sp, float) {
+  int p[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) p[j] = b[sp->ofs[j]];
+  const int c = p[5] - p[6] - p[9] + p[10];
+  const int lbp = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
+                  (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
+                  (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
+                  (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
+  const int word = sp->subset[lbp >> 5];  // data-dependent word: read it from the table, not from a register copy
+  return (double)((word & (1 << (lbp & 31))) ? sp->left : sp->right);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+template <int STEP, bool HAAR>
+__device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const int4 T, const ScaleDev& S) {
+  using Stump = typename std::conditional<HAAR, HaarStumpDev, LbpStumpDev>::type;
   const TileGeom<STEP> G(A.W0, A.H0);
+  float* s_vnf = reinterpret_cast<float*>(lds + G.words());
+  unsigned short* s_q = reinterpret_cast<unsigned short*>(s_vnf + TILE_WINDOWS);  // two buffers of TILE_WINDOWS
+  int* s_cnt = reinterpret_cast<int*>(s_q + 2 * TILE_WINDOWS);                   // [stage] = windows that reached it
   const int frame = blockIdx.y;
   const int32_t* sum = A.integ + ((size_t)frame * A.nchan + 0) * A.int_frame_elems + S.int_ofs;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gx = T.y * TILE_X + lane;
-  stage_tile<STEP>(lds, G, sum, S, T.y * TILE_X * STEP, T.z * TILE_Y * STEP);
+  // the wave index is the same in all 64 lanes; say so, or every loop bounded by it is compiled as divergent
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gx0 = T.y * TILE_X, gy0 = T.z * TILE_Y;
+  const Stump CC_CONST* stumps = as_const_table(reinterpret_cast<const Stump*>(STEP == 2 ? A.stumps2 : A.stumps1));
+  const int CC_CONST* stage_first = as_const_table(A.stage_first);
+  const int CC_CONST* stage_ntrees = as_const_table(A.stage_ntrees);
+  const float CC_CONST* stage_thr = as_const_table(A.stage_thr);
+  const bool dbg = A.dbg_codes != nullptr && frame == 0;
+
+  stage_tile<STEP>(lds, G, sum, S, gx0 * STEP, gy0 * STEP);
+  if (threadIdx.x < MAX_STAGES) s_cnt[threadIdx.x] = 0;
   __syncthreads();
 
-  int base[WIN_PER_THREAD];
-  bool alive[WIN_PER_THREAD];
-  int code[WIN_PER_THREAD];
-  double last[WIN_PER_THREAD];
-#pragma unroll
-  for (int k = 0; k < WIN_PER_THREAD; k++) {
-    const int ly = wave * WIN_PER_THREAD + k;
-    base[k] = (ly * STEP) * G.row_stride + lane;
-    alive[k] = gx < S.nx && (T.z * TILE_Y + ly) < S.ny;
-    code[k] = -1;
-    last[k] = 0.0;
-  }
-  const LbpStumpDev* __restrict__ stumps = reinterpret_cast<const LbpStumpDev*>(STEP == 2 ? A.stumps2 : A.stumps1);
-  int si = 0;
-  bool rej0[WIN_PER_THREAD] = {false, false, false, false};
-  for (int st = 0; st < A.nstages; st++) {
-    const bool any_mine = alive[0] | alive[1] | alive[2] | alive[3];
-    if (!__any(any_mine)) break;
-    const int nt = A.stage_ntrees[st];
-    double acc[WIN_PER_THREAD] = {0., 0., 0., 0.};
-    for (int i = 0; i < nt; i++, si++) {
-      const LbpStumpDev* sp = stumps + si;
-#pragma unroll
-      for (int k = 0; k < WIN_PER_THREAD; k++) {
-        const int32_t* b = lds + base[k];
-        int p[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) p[j] = b[sp->ofs[j]];
-        const int c = p[5] - p[6] - p[9] + p[10];
-        const int lbp = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
-                        (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
-                        (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
-                        (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
-        const int word = reinterpret_cast<const int*>(sp->subset)[lbp >> 5];
-        acc[k] += (double)((word & (1 << (lbp & 31))) ? sp->left : sp->right);
-      }
-    }
-    const double thr = (double)A.stage_thr[st];
+  auto window_base = [&](int id) { return ((id >> 6) * STEP) * G.row_stride + (id & 63); };
+  auto report = [&](int id, int code, double last) {  // parity instrumentation
+    const size_t o = (size_t)S.win_ofs + (size_t)(gy0 + (id >> 6)) * S.nx + (gx0 + (id & 63));
+    A.dbg_codes[o] = code;
+    if (A.dbg_sums) A.dbg_sums[o] = last;
+  };
+  auto emit_candidate = [&](int id) {
+    const int slot = atomicAdd(A.cand_count, 1);
+    if (slot < A.cand_cap) A.cands[slot] = CandRaw{frame, T.x, gx0 + (id & 63), gy0 + (id >> 6)};
+  };
+  // appends the calling lanes with `pass` to the queue of stage `st` (whole wavefront must call)
+  auto enqueue = [&](bool pass, int id, int st) {
+    const unsigned long long m = __ballot(pass);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&s_cnt[st], __popcll(m));
+    base = __shfl(base, 0);
+    if (pass) s_q[(st & 1) * TILE_WINDOWS + base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)id;
+  };
+
+  // ---------------- phase D: variance test + stage 0, 4 window rows per thread --------------------------------
+  {
+    int base[WIN_PER_THREAD];
+    float vnf[WIN_PER_THREAD];
+    bool alive[WIN_PER_THREAD];
+    const int gx = gx0 + lane;
 #pragma unroll
     for (int k = 0; k < WIN_PER_THREAD; k++) {
-      if (alive[k]) {
-        last[k] = acc[k];
-        if (acc[k] < thr) {
-          alive[k] = false;
-          code[k] = -st;
-          if (st == 0) rej0[k] = true;
+      const int ly = wave * WIN_PER_THREAD + k;
+      const int gy = gy0 + ly;
+      base[k] = (ly * STEP) * G.row_stride + lane;
+      vnf[k] = 1.f;
+      alive[k] = gx < S.nx && gy < S.ny;
+      if (HAAR) {
+        const bool in_grid = alive[k];
+        alive[k] = false;
+        if (in_grid) {
+          const unsigned* sq = reinterpret_cast<const unsigned*>(A.integ + ((size_t)frame * A.nchan + 1) * A.int_frame_elems + S.int_ofs);
+          const int nrx = A.W0 - 2, nry = A.H0 - 2;
+          const double area = (double)(nrx * nry);
+          const int32_t* b = lds + base[k];
+          const int valsum = b[G.at(1, 1)] - b[G.at(1, 1 + nrx)] - b[G.at(1 + nry, 1)] + b[G.at(1 + nry, 1 + nrx)];
+          const size_t q0 = (size_t)(gy * STEP + 1) * S.pitchI + (gx * STEP + 1);
+          const unsigned valsq = sq[q0] - sq[q0 + nrx] - sq[q0 + (size_t)nry * S.pitchI] + sq[q0 + (size_t)nry * S.pitchI + nrx];
+          double nf = area * (double)valsq - (double)valsum * (double)valsum;
+          if (nf > 0.) {
+            nf = sqrt(nf);
+            vnf[k] = (float)(1. / nf);
+            alive[k] = area * (double)vnf[k] < 1e-1;
+          }
+          if (dbg && !alive[k]) report(ly * 64 + lane, -1, 0.0);
         }
       }
     }
-  }
+    const bool any_mine = alive[0] | alive[1] | alive[2] | alive[3];
+    double acc[WIN_PER_THREAD] = {0., 0., 0., 0.};
+    if (__any(any_mine)) {
+      const int nt = stage_ntrees[0];
+      for (int i = 0; i < nt; i++) {
 #pragma unroll
-  for (int k = 0; k < WIN_PER_THREAD; k++) {
-    const int gy = T.z * TILE_Y + wave * WIN_PER_THREAD + k;
-    const unsigned long long m = __ballot(rej0[k]);
-    if (gy < S.ny) {
-      if (lane == 0) A.masks[(size_t)frame * A.mask_frame_words + S.mask_ofs + (size_t)gy * S.nxw + T.y] = m;
-      if (gx < S.nx) {
-        if (alive[k]) {
-          code[k] = 1;
-          const int slot = atomicAdd(A.cand_count, 1);
-          if (slot < A.cand_cap) A.cands[slot] = CandRaw{frame, T.x, gx, gy};
+        for (int k = 0; k < WIN_PER_THREAD; k++) acc[k] += stump_vote(lds + base[k], stumps + i, vnf[k]);
+      }
+    }
+    const double thr = (double)stage_thr[0];
+#pragma unroll
+    for (int k = 0; k < WIN_PER_THREAD; k++) {
+      const int ly = wave * WIN_PER_THREAD + k;
+      const int gy = gy0 + ly;
+      const int id = ly * 64 + lane;
+      const bool pass = alive[k] && !(acc[k] < thr);
+      const bool rej0 = alive[k] && !pass;
+      const unsigned long long m = __ballot(rej0);
+      if (lane == 0 && gy < S.ny) A.masks[(size_t)frame * A.mask_frame_words + S.mask_ofs + (size_t)gy * S.nxw + T.y] = m;
+      if (dbg && rej0) report(id, 0, acc[k]);
+      if (A.nstages == 1) {
+        if (pass) {
+          emit_candidate(id);
+          if (dbg) report(id, 1, acc[k]);
         }
-        if (A.dbg_codes && frame == 0) {
-          const size_t o = (size_t)S.win_ofs + (size_t)gy * S.nx + gx;
-          A.dbg_codes[o] = code[k];
-          if (A.dbg_sums) A.dbg_sums[o] = last[k];
+      } else {
+        if (pass) s_vnf[id] = vnf[k];
+        enqueue(pass, id, 1);
+      }
+    }
+  }
+
+  // ---------------- phase T: one thread per queued window, stage by stage -------------------------------------
+  int st = 1;
+  int n = 0;
+  for (; st < A.nstages; st++) {
+    __syncthreads();  // queue of stage st complete; previous readers of the buffer it overwrites are done
+    n = s_cnt[st];
+    if (n == 0 || n < A.wave_below) break;
+    const unsigned short* q = s_q + (st & 1) * TILE_WINDOWS;
+    const int first = stage_first[st], nt = stage_ntrees[st];
+    const double thr = (double)stage_thr[st];
+    const bool last_stage = st == A.nstages - 1;
+    for (int i0 = wave * 64; i0 < n; i0 += 256) {  // wave-uniform trip count
+      const int i = i0 + lane;
+      const bool valid = i < n;
+      const int id = valid ? q[i] : 0;
+      const int32_t* b = lds + window_base(id);
+      const float vnf = HAAR ? s_vnf[id] : 1.f;
+      double acc = 0.;
+      for (int j = 0; j < nt; j++) acc += stump_vote(b, stumps + first + j, vnf);
+      const bool pass = valid && !(acc < thr);
+      if (dbg && valid && !pass) report(id, -st, acc);
+      if (last_stage) {
+        if (pass) {
+          emit_candidate(id);
+          if (dbg) report(id, 1, acc);
         }
+      } else
+        enqueue(pass, id, st + 1);
+    }
+  }
+  if (st >= A.nstages || n == 0) return;
+
+  // ---------------- phase W: one wavefront per window, lanes split the stumps ---------------------------------
+  {
+    const unsigned short* q = s_q + (st & 1) * TILE_WINDOWS;
+    for (int i = wave; i < n; i += 4) {
+      const int id = q[i];
+      const int32_t* b = lds + window_base(id);
+      const float vnf = HAAR ? s_vnf[id] : 1.f;
+      int s2 = st;
+      double total = 0.;
+      for (; s2 < A.nstages; s2++) {
+        const int first = stage_first[s2], nt = stage_ntrees[s2];
+        double part = 0.;
+        for (int j = lane; j < nt; j += 64) part += stump_vote(b, stumps + first + j, vnf);
+        total = wave_sum_f64(part);
+        if (total < (double)stage_thr[s2]) break;
+      }
+      if (lane == 0) {
+        if (s2 == A.nstages) emit_candidate(id);
+        if (dbg) report(id, s2 == A.nstages ? 1 : -s2, total);
       }
     }
   }
@@ -498,22 +535,22 @@ __device__ __forceinline__ void eval_lbp_tile(const EvalArgs& A, int32_t* lds, c
 // One launch covers every scale: the tile's scale decides (block-uniformly) which layout it uses.
 __global__ __launch_bounds__(256) void k_eval_haar(EvalArgs A) {
   extern __shared__ int32_t lds[];
-  const int4 T = A.tiles[blockIdx.x];
-  const ScaleDev S = A.sd[T.x];
+  const int4 T = load_record(as_const_table(A.tiles) + blockIdx.x);
+  const ScaleDev S = load_record(as_const_table(A.sd) + T.x);
   if (S.ystep == 2)
-    eval_haar_tile<2>(A, lds, T, S);
+    eval_tile<2, true>(A, lds, T, S);
   else
-    eval_haar_tile<1>(A, lds, T, S);
+    eval_tile<1, true>(A, lds, T, S);
 }
 
 __global__ __launch_bounds__(256) void k_eval_lbp(EvalArgs A) {
   extern __shared__ int32_t lds[];
-  const int4 T = A.tiles[blockIdx.x];
-  const ScaleDev S = A.sd[T.x];
+  const int4 T = load_record(as_const_table(A.tiles) + blockIdx.x);
+  const ScaleDev S = load_record(as_const_table(A.sd) + T.x);
   if (S.ystep == 2)
-    eval_lbp_tile<2>(A, lds, T, S);
+    eval_tile<2, false>(A, lds, T, S);
   else
-    eval_lbp_tile<1>(A, lds, T, S);
+    eval_tile<1, false>(A, lds, T, S);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -630,8 +667,9 @@ struct cc_detector {
   int max_batch = 1;
   hipStream_t own_stream = nullptr, stream = nullptr;
   // cascade tables on the device (one per tile layout)
-  DevBuf<int> d_stage_ntrees;
+  DevBuf<int> d_stage_ntrees, d_stage_first;
   DevBuf<float> d_stage_thr;
+  int wave_below = 0;
   DevBuf<HaarStumpDev> d_haar1, d_haar2;
   DevBuf<LbpStumpDev> d_lbp1, d_lbp2;
   size_t lds = 0;  // dynamic LDS bytes per tile (larger of the two layouts)
@@ -672,6 +710,34 @@ static cc_status ensure_device(int device) {
   if (device < 0 || device >= n) return set_error(CC_ERR_INVALID_ARG, "device %d out of range (devices: %d)", device, n);
   CC_HIP(hipSetDevice(device));
   return CC_OK;
+}
+
+// True when, for every stage, any partial sum of leaf values is exactly representable in double: all leaves are
+// integer multiples of q = 2^(emin-23) (emin = smallest exponent among the stage's nonzero leaves) and the sum of the
+// larger leaf magnitudes divided by q stays below 2^53. Then the double accumulation never rounds, so its result
+// does not depend on the order of the additions.
+static bool stage_sums_order_independent(const Cascade& m) {
+  for (size_t s = 0; s < m.stage_ntrees.size(); s++) {
+    int emin = INT32_MAX;
+    double mag = 0;
+    for (int i = 0; i < m.stage_ntrees[s]; i++) {
+      const size_t k = (size_t)m.stage_first[s] + i;
+      const float l = m.stump_left[k], r = m.stump_right[k];
+      if (!std::isfinite(l) || !std::isfinite(r)) return false;
+      mag += std::max(std::fabs((double)l), std::fabs((double)r));
+      for (float v : {l, r})
+        if (v != 0.0f) {
+          int e;
+          std::frexp(v, &e);
+          emin = std::min(emin, e);
+        }
+    }
+    if (emin == INT32_MAX) continue;
+    // v = f * 2^e with f in [0.5, 1) and a 24-bit significand: v is a multiple of 2^(e-24); subnormals only get coarser
+    const double q = std::ldexp(1.0, emin - 24);
+    if (mag / q >= 9007199254740992.0) return false;
+  }
+  return true;
 }
 
 template <int STEP>
@@ -895,7 +961,9 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.W0 = d->m.win_w;
     A.H0 = d->m.win_h;
     A.nstages = (int)d->m.stage_ntrees.size();
+    A.stage_first = d->d_stage_first.p;
     A.stage_ntrees = d->d_stage_ntrees.p;
+    A.wave_below = d->wave_below;
     A.stage_thr = d->d_stage_thr.p;
     A.masks = d->d_masks.p;
     A.mask_frame_words = P->mask_frame_words;
@@ -1032,7 +1100,10 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   d->stream = d->own_stream;
   const TileGeom<1> G1(d->m.win_w, d->m.win_h);
   const TileGeom<2> G2(d->m.win_w, d->m.win_h);
-  d->lds = (size_t)std::max(G1.words(), G2.words()) * 4;
+  d->lds = eval_lds_bytes(std::max(G1.words(), G2.words()));
+  if ((int)d->m.stage_ntrees.size() >= MAX_STAGES)
+    return set_error(CC_ERR_UNSUPPORTED, "cc_detector_create: cascades with %zu stages are not supported (limit %d)",
+                     d->m.stage_ntrees.size(), MAX_STAGES - 1);
   if (d->lds > 160 * 1024 - 256)
     return set_error(CC_ERR_UNSUPPORTED, "cc_detector_create: %dx%d window needs %zu bytes of LDS per tile (limit 160 KiB)",
                      d->m.win_w, d->m.win_h, d->lds);
@@ -1044,7 +1115,12 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
       CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_lbp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds));
   }
   std::vector<int> ntrees(d->m.stage_ntrees.begin(), d->m.stage_ntrees.end());
+  std::vector<int> sfirst(d->m.stage_first.begin(), d->m.stage_first.end());
   CC_HIP(d->d_stage_ntrees.upload(ntrees, d->stream));
+  CC_HIP(d->d_stage_first.upload(sfirst, d->stream));
+  // One wavefront per window (parallel reduction of a stage's votes) is only bit-identical to the sequential CPU sum
+  // when every partial sum is exact in double; LBP stages are too short for it to pay.
+  d->wave_below = (haar && stage_sums_order_independent(d->m)) ? 16 : 0;
   CC_HIP(d->d_stage_thr.upload(d->m.stage_threshold, d->stream));
   if (haar) {
     std::vector<HaarStumpDev> s1, s2;

@@ -118,10 +118,19 @@ void group_rectangles(std::vector<cc_rect>& rects, int group_threshold, double e
     }
     return r;
   };
-  for (int i = 0; i < n; i++) {
+  // SimilarRects needs |a.x - b.x| <= delta <= eps * (a.w + a.h) / 2, so after sorting by x only a short run of
+  // followers can be similar to a rectangle: a sweep instead of all n^2 pairs (same components, same labels).
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return rects[a].x < rects[b].x; });
+  for (int oi = 0; oi < n; oi++) {
+    const int i = order[oi];
     const cc_rect& a = rects[i];
-    for (int j = i + 1; j < n; j++) {
+    const double reach = eps * (a.width + a.height) * 0.5;
+    for (int oj = oi + 1; oj < n; oj++) {
+      const int j = order[oj];
       const cc_rect& b = rects[j];
+      if (b.x - a.x > reach) break;
       const double delta = eps * (std::min(a.width, b.width) + std::min(a.height, b.height)) * 0.5;
       if (std::abs(a.x - b.x) <= delta && std::abs(a.y - b.y) <= delta &&
           std::abs(a.x + a.width - b.x - b.width) <= delta && std::abs(a.y + a.height - b.y - b.height) <= delta) {
