@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -51,7 +52,9 @@ __device__ __forceinline__ T load_record(const T CC_CONST* p) {
 
 constexpr int TILE_X = 64;   // window origins per tile row = one wavefront = one rej0 mask word
 constexpr int TILE_Y = 16;   // window origin rows per tile
-constexpr int WIN_PER_THREAD = 4;  // 4 waves x 4 rows
+constexpr int EVAL_THREADS = 512;  // 8 wavefronts share one LDS tile (more waves per LDS byte = better latency hiding)
+constexpr int EVAL_WAVES = EVAL_THREADS / 64;
+constexpr int WIN_PER_THREAD = TILE_Y / EVAL_WAVES;  // window rows per thread in the dense phase
 
 struct ScaleDev {
   int w, h;
@@ -260,11 +263,11 @@ __global__ void k_tilted_from_sum(const int32_t* __restrict__ sum, int pitchI, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: cascade evaluation. Block = 256 threads = 4 wavefronts = one tile of 64 x 16 window origins of one scale.
+// K4: cascade evaluation. Block = 512 threads = 8 wavefronts = one tile of 64 x 16 window origins of one scale.
 // The tile of the `sum` integral the windows touch is staged once into LDS (for STEP 2 with even and odd columns
 // in separate planes, so that a wavefront's stride-2 corner reads are bank-conflict free); every rectangle corner
 // is then an LDS read. The cascade's early exit is handled by COMPACTION instead of divergence:
-//   phase D (dense)  : lane = window column, 4 window rows per thread: variance test + stage 0 for all 1024 windows;
+//   phase D (dense)  : lane = window column, 2 window rows per thread: variance test + stage 0 for all 1024 windows;
 //                      wave ballots give the stage-0 rejection mask words; survivors are appended to an LDS queue
 //                      (wave ballot + one LDS atomic per wave);
 //   phase T (thread) : stage by stage, one thread per queued window (full wavefronts), survivors re-queued into the
@@ -292,16 +295,17 @@ struct TileGeom {
 
 constexpr int TILE_WINDOWS = TILE_X * TILE_Y;  // 1024
 constexpr int MAX_STAGES = 64;                 // per-stage queue counters live in LDS
-// LDS bytes per block: integral tile + vnf[1024] + 2 queues of u16[1024] + int counters[MAX_STAGES]
+constexpr int PART_DOUBLES = 7 * 64;           // partial stage sums of the stump-split phase: (slices-1) x windows
+// LDS bytes per block: integral tile (padded to 8 B) + partial sums + vnf[1024] + 2 queues of u16[1024] + counters
 __host__ __device__ inline size_t eval_lds_bytes(int tile_words) {
-  return (size_t)tile_words * 4 + TILE_WINDOWS * 4 + 2 * TILE_WINDOWS * 2 + MAX_STAGES * 4;
+  return (size_t)((tile_words + 1) & ~1) * 4 + PART_DOUBLES * 8 + TILE_WINDOWS * 4 + 2 * TILE_WINDOWS * 2 + MAX_STAGES * 4;
 }
 
 template <int STEP>
 __device__ __forceinline__ void stage_tile(int32_t* lds, const TileGeom<STEP>& G, const int32_t* __restrict__ sum,
                                            const ScaleDev& S, int x0, int y0) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int r = wave; r < G.rows; r += 4) {
+  for (int r = wave; r < G.rows; r += EVAL_WAVES) {
     const int gr = y0 + r;
     const int32_t* src = sum + (size_t)gr * S.pitchI;
     for (int c = lane; c < G.cols; c += 64) {
@@ -327,6 +331,8 @@ struct EvalArgs {
   const void* stumps1;  // stump tables in STEP-1 / STEP-2 tile coordinates
   const void* stumps2;
   int wave_below;       // switch to one wavefront per window when fewer windows than this are queued (0 = never)
+  int split_stumps;     // stage sums are exact (order-independent): wavefronts may split a stage's stumps
+  int stop_after;       // timing experiments only: drop every window still alive after this stage (-1 = off)
   unsigned long long* masks;
   size_t mask_frame_words;
   CandRaw* cands;
@@ -337,8 +343,7 @@ struct EvalArgs {
 };
 
 // ---- one weak classifier on one window; `b` = LDS address of the window's tile base ----------------------------
-__device__ __forceinline__ double stump_vote(const int32_t* b, const HaarStumpDev CC_CONST* spp, float vnf) {
-  const HaarStumpDev sp = load_record(spp);
+__device__ __forceinline__ double stump_vote(const int32_t* b, const HaarStumpDev& sp, float vnf) {
   const int r0 = b[sp.ofs[0][0]] - b[sp.ofs[0][1]] - b[sp.ofs[0][2]] + b[sp.ofs[0][3]];
   const int r1 = b[sp.ofs[1][0]] - b[sp.ofs[1][1]] - b[sp.ofs[1][2]] + b[sp.ofs[1][3]];
   float v = sp.w[0] * (float)r0 + sp.w[1] * (float)r1;
@@ -348,6 +353,9 @@ __device__ __forceinline__ double stump_vote(const int32_t* b, const HaarStumpDe
   }
   v *= vnf;
   return (double)(v < sp.thr ? sp.left : sp.right);
+}
+__device__ __forceinline__ double stump_vote(const int32_t* b, const HaarStumpDev CC_CONST* spp, float vnf) {
+  return stump_vote(b, load_record(spp), vnf);
 }
 
 __device__ __forceinline__ double stump_vote(const int32_t* b, const LbpStumpDev CC_CONST* sp, float) {
@@ -363,17 +371,35 @@ __device__ __forceinline__ double stump_vote(const int32_t* b, const LbpStumpDev
   return (double)((word & (1 << (lbp & 31))) ? sp->left : sp->right);
 }
 
+// Sum of `v` over the 64 lanes, returned wave-uniform (in scalar registers). Cross-lane moves are DPP modifiers
+// (quad permutes, row mirrors, row broadcasts), not LDS permutes: ~6 short steps. The order of the additions differs
+// from a sequential sum, so callers use it only where the sum is exact (order-independent).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long u = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xF, false);
+  return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  return v;
+  v += dpp_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_f64<0x140, 0xF>(v);  // row_mirror: every lane now holds the total of its row of 16
+  v += dpp_f64<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3 (masked rows add 0)
+  v += dpp_f64<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the wave total
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, 63);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
 template <int STEP, bool HAAR>
 __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const int4 T, const ScaleDev& S) {
   using Stump = typename std::conditional<HAAR, HaarStumpDev, LbpStumpDev>::type;
   const TileGeom<STEP> G(A.W0, A.H0);
-  float* s_vnf = reinterpret_cast<float*>(lds + G.words());
+  double* s_part = reinterpret_cast<double*>(lds + ((G.words() + 1) & ~1));
+  float* s_vnf = reinterpret_cast<float*>(s_part + PART_DOUBLES);
   unsigned short* s_q = reinterpret_cast<unsigned short*>(s_vnf + TILE_WINDOWS);  // two buffers of TILE_WINDOWS
   int* s_cnt = reinterpret_cast<int*>(s_q + 2 * TILE_WINDOWS);                   // [stage] = windows that reached it
   const int frame = blockIdx.y;
@@ -391,6 +417,7 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
   if (threadIdx.x < MAX_STAGES) s_cnt[threadIdx.x] = 0;
   __syncthreads();
 
+  if (A.stop_after == -2) return;  // timing experiments: tile staging only
   auto window_base = [&](int id) { return ((id >> 6) * STEP) * G.row_stride + (id & 63); };
   auto report = [&](int id, int code, double last) {  // parity instrumentation
     const size_t o = (size_t)S.win_ofs + (size_t)(gy0 + (id >> 6)) * S.nx + (gx0 + (id & 63));
@@ -444,13 +471,36 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
         }
       }
     }
-    const bool any_mine = alive[0] | alive[1] | alive[2] | alive[3];
-    double acc[WIN_PER_THREAD] = {0., 0., 0., 0.};
+    if (A.stop_after == -3) {  // timing experiments: staging + variance test only
+      float sink = 0;
+#pragma unroll
+      for (int k = 0; k < WIN_PER_THREAD; k++) sink += alive[k] ? vnf[k] : 0.f;
+      if (sink == 12345.f) s_vnf[0] = sink;
+      return;
+    }
+    bool any_mine = false;
+    double acc[WIN_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < WIN_PER_THREAD; k++) {
+      any_mine |= alive[k];
+      acc[k] = 0.;
+    }
     if (__any(any_mine)) {
       const int nt = stage_ntrees[0];
-      for (int i = 0; i < nt; i++) {
+      if constexpr (HAAR) {
+        // software pipeline: the next stump record is fetched (scalar loads) while this one is evaluated
+        Stump cur = load_record(stumps);
+        for (int i = 0; i < nt; i++) {
+          const Stump nxt = load_record(stumps + min(i + 1, nt - 1));
 #pragma unroll
-        for (int k = 0; k < WIN_PER_THREAD; k++) acc[k] += stump_vote(lds + base[k], stumps + i, vnf[k]);
+          for (int k = 0; k < WIN_PER_THREAD; k++) acc[k] += stump_vote(lds + base[k], cur, vnf[k]);
+          cur = nxt;
+        }
+      } else {
+        for (int i = 0; i < nt; i++) {
+#pragma unroll
+          for (int k = 0; k < WIN_PER_THREAD; k++) acc[k] += stump_vote(lds + base[k], stumps + i, vnf[k]);
+        }
       }
     }
     const double thr = (double)stage_thr[0];
@@ -477,9 +527,13 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
   }
 
   // ---------------- phase T: one thread per queued window, stage by stage -------------------------------------
+  // With fewer than 4*64 windows queued and order-independent (exact) stage sums, the 8 wavefronts also SPLIT THE
+  // STUMPS of the stage (slices j = slice, slice+ns, ...): the partial sums meet in LDS and slice 0 finishes the
+  // window. This keeps all wavefronts busy through the long late stages instead of leaving one wave to walk them.
   int st = 1;
   int n = 0;
   for (; st < A.nstages; st++) {
+    if (A.stop_after >= 0 && st > A.stop_after) return;
     __syncthreads();  // queue of stage st complete; previous readers of the buffer it overwrites are done
     n = s_cnt[st];
     if (n == 0 || n < A.wave_below) break;
@@ -487,14 +541,10 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
     const int first = stage_first[st], nt = stage_ntrees[st];
     const double thr = (double)stage_thr[st];
     const bool last_stage = st == A.nstages - 1;
-    for (int i0 = wave * 64; i0 < n; i0 += 256) {  // wave-uniform trip count
-      const int i = i0 + lane;
-      const bool valid = i < n;
-      const int id = valid ? q[i] : 0;
-      const int32_t* b = lds + window_base(id);
-      const float vnf = HAAR ? s_vnf[id] : 1.f;
-      double acc = 0.;
-      for (int j = 0; j < nt; j++) acc += stump_vote(b, stumps + first + j, vnf);
+    const int groups = (n + 63) >> 6;  // wavefronts needed to give every window a lane
+    int ns = 1;                        // stump slices
+    if (A.split_stumps) ns = groups <= 1 ? 8 : groups <= 2 ? 4 : groups <= 4 ? 2 : 1;
+    auto finish = [&](bool valid, int id, double acc) {  // whole wavefront calls
       const bool pass = valid && !(acc < thr);
       if (dbg && valid && !pass) report(id, -st, acc);
       if (last_stage) {
@@ -504,6 +554,55 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
         }
       } else
         enqueue(pass, id, st + 1);
+    };
+    if (ns == 1) {
+      for (int i0 = wave * 64; i0 < n; i0 += EVAL_THREADS) {  // wave-uniform trip count
+        const int i = i0 + lane;
+        const bool valid = i < n;
+        const int id = valid ? q[i] : 0;
+        const int32_t* b = lds + window_base(id);
+        const float vnf = HAAR ? s_vnf[id] : 1.f;
+        double acc = 0.;
+        if constexpr (HAAR) {
+          Stump cur = load_record(stumps + first);
+          for (int j = 0; j < nt; j++) {
+            const Stump nxt = load_record(stumps + first + min(j + 1, nt - 1));
+            acc += stump_vote(b, cur, vnf);
+            cur = nxt;
+          }
+        } else {
+          for (int j = 0; j < nt; j++) acc += stump_vote(b, stumps + first + j, vnf);
+        }
+        finish(valid, id, acc);
+      }
+    } else {
+      const int slice = wave % ns, grp = wave / ns;  // EVAL_WAVES / ns groups >= `groups`
+      const int i = grp * 64 + lane;
+      const bool valid = i < n;
+      const int id = valid ? q[i] : 0;
+      double acc = 0.;
+      if (grp < groups) {
+        const int32_t* b = lds + window_base(id);
+        const float vnf = HAAR ? s_vnf[id] : 1.f;
+        if constexpr (HAAR) {
+          if (slice < nt) {
+            Stump cur = load_record(stumps + first + slice);
+            for (int j = slice; j < nt; j += ns) {
+              const Stump nxt = load_record(stumps + first + min(j + ns, nt - 1));
+              acc += stump_vote(b, cur, vnf);
+              cur = nxt;
+            }
+          }
+        } else {
+          for (int j = slice; j < nt; j += ns) acc += stump_vote(b, stumps + first + j, vnf);
+        }
+        if (slice) s_part[(slice - 1) * (EVAL_THREADS / ns) + i] = acc;  // <= 7 * 64 entries for every ns
+      }
+      __syncthreads();  // partial sums visible
+      if (grp < groups && slice == 0) {
+        for (int k = 1; k < ns; k++) acc += s_part[(k - 1) * (EVAL_THREADS / ns) + i];
+        finish(valid, id, acc);
+      }
     }
   }
   if (st >= A.nstages || n == 0) return;
@@ -511,13 +610,14 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
   // ---------------- phase W: one wavefront per window, lanes split the stumps ---------------------------------
   {
     const unsigned short* q = s_q + (st & 1) * TILE_WINDOWS;
-    for (int i = wave; i < n; i += 4) {
+    for (int i = wave; i < n; i += EVAL_WAVES) {
       const int id = q[i];
       const int32_t* b = lds + window_base(id);
       const float vnf = HAAR ? s_vnf[id] : 1.f;
       int s2 = st;
       double total = 0.;
       for (; s2 < A.nstages; s2++) {
+        if (A.stop_after >= 0 && s2 > A.stop_after) break;
         const int first = stage_first[s2], nt = stage_ntrees[s2];
         double part = 0.;
         for (int j = lane; j < nt; j += 64) part += stump_vote(b, stumps + first + j, vnf);
@@ -533,8 +633,8 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
 }
 
 // One launch covers every scale: the tile's scale decides (block-uniformly) which layout it uses.
-__global__ __launch_bounds__(256) void k_eval_haar(EvalArgs A) {
-  extern __shared__ int32_t lds[];
+__global__ __launch_bounds__(EVAL_THREADS) void k_eval_haar(EvalArgs A) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const int4 T = load_record(as_const_table(A.tiles) + blockIdx.x);
   const ScaleDev S = load_record(as_const_table(A.sd) + T.x);
   if (S.ystep == 2)
@@ -543,8 +643,8 @@ __global__ __launch_bounds__(256) void k_eval_haar(EvalArgs A) {
     eval_tile<1, true>(A, lds, T, S);
 }
 
-__global__ __launch_bounds__(256) void k_eval_lbp(EvalArgs A) {
-  extern __shared__ int32_t lds[];
+__global__ __launch_bounds__(EVAL_THREADS) void k_eval_lbp(EvalArgs A) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const int4 T = load_record(as_const_table(A.tiles) + blockIdx.x);
   const ScaleDev S = load_record(as_const_table(A.sd) + T.x);
   if (S.ystep == 2)
@@ -670,6 +770,8 @@ struct cc_detector {
   DevBuf<int> d_stage_ntrees, d_stage_first;
   DevBuf<float> d_stage_thr;
   int wave_below = 0;
+  int stop_after = -1;
+  int split_stumps = 0;
   DevBuf<HaarStumpDev> d_haar1, d_haar2;
   DevBuf<LbpStumpDev> d_lbp1, d_lbp2;
   size_t lds = 0;  // dynamic LDS bytes per tile (larger of the two layouts)
@@ -964,6 +1066,8 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.stage_first = d->d_stage_first.p;
     A.stage_ntrees = d->d_stage_ntrees.p;
     A.wave_below = d->wave_below;
+    A.stop_after = d->stop_after;
+    A.split_stumps = d->split_stumps;
     A.stage_thr = d->d_stage_thr.p;
     A.masks = d->d_masks.p;
     A.mask_frame_words = P->mask_frame_words;
@@ -977,9 +1081,9 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.stumps2 = haar ? (const void*)d->d_haar2.p : (const void*)d->d_lbp2.p;
     if (P->n_tiles) {
       if (haar)
-        hipLaunchKernelGGL(k_eval_haar, dim3(P->n_tiles, nf), dim3(256), d->lds, st, A);
+        hipLaunchKernelGGL(k_eval_haar, dim3(P->n_tiles, nf), dim3(EVAL_THREADS), d->lds, st, A);
       else
-        hipLaunchKernelGGL(k_eval_lbp, dim3(P->n_tiles, nf), dim3(256), d->lds, st, A);
+        hipLaunchKernelGGL(k_eval_lbp, dim3(P->n_tiles, nf), dim3(EVAL_THREADS), d->lds, st, A);
     }
   }
   {
@@ -1120,7 +1224,13 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   CC_HIP(d->d_stage_first.upload(sfirst, d->stream));
   // One wavefront per window (parallel reduction of a stage's votes) is only bit-identical to the sequential CPU sum
   // when every partial sum is exact in double; LBP stages are too short for it to pay.
-  d->wave_below = (haar && stage_sums_order_independent(d->m)) ? 16 : 0;
+  const bool exact = stage_sums_order_independent(d->m);
+  d->wave_below = (haar && exact) ? 24 : 0;
+  d->split_stumps = exact ? 1 : 0;
+  if (const char* e = std::getenv("CCAMD_SPLIT_STUMPS")) d->split_stumps = d->split_stumps && std::atoi(e) != 0;
+  if (const char* e = std::getenv("CCAMD_DEBUG_STOP_AFTER_STAGE")) d->stop_after = std::atoi(e);  // timing experiments
+  if (const char* e = std::getenv("CCAMD_WAVE_BELOW"))  // tuning knob; only honoured when the reduction is exact
+    if (d->wave_below) d->wave_below = std::max(0, std::atoi(e));
   CC_HIP(d->d_stage_thr.upload(d->m.stage_threshold, d->stream));
   if (haar) {
     std::vector<HaarStumpDev> s1, s2;
