@@ -1,0 +1,165 @@
+// C++ host adaptor: the reference's feature-evaluator plugin surface (same class names, virtuals, argument meaning and
+// error behaviour as traincascade/lib/include/traincascade_features.h:131-188, haarfeatures.h:31-122,
+// lbpfeatures.h:22-83) implemented on top of the C ABI of include/cascadeclassifier_amd.h, i.e. on the HIP kernels.
+// A trainer built against the reference headers can switch to these by changing the include path: CvCascadeClassifier
+// keeps owning a cv::Ptr<CvFeatureEvaluator>, CvCascadeBoostTrainData keeps calling operator()(featureIdx, sampleIdx).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../../include/cascadeclassifier_amd.h"
+#include "cv_compat.hpp"
+
+#define FEATURES "features"
+#define CC_MAX_CAT_COUNT "maxCatCount"
+#define CC_FEATURE_SIZE "featSize"
+#define CC_MODE "mode"
+#define CC_MODE_BASIC "BASIC"
+#define CC_MODE_CORE "CORE"
+#define CC_MODE_ALL "ALL"
+#define CC_RECTS "rects"
+#define CC_TILTED "tilted"
+#define CC_RECT "rect"
+#define CV_HAAR_FEATURE_MAX 3
+
+// traincascade_features.h:131-144 (the CvParams read/scanAttr/print machinery is trainer plumbing, out of scope)
+class CvFeatureParams {
+ public:
+  enum { HAAR = 0, LBP = 1, HOG = 2 };
+  CvFeatureParams() : maxCatCount(0), featSize(1) {}
+  virtual ~CvFeatureParams() {}
+  virtual void init(const CvFeatureParams& fp) {
+    maxCatCount = fp.maxCatCount;
+    featSize = fp.featSize;
+  }
+  virtual void write(cv::FileStorage& fs) const;
+  static cv::Ptr<CvFeatureParams> create(int featureType);
+  int maxCatCount;
+  int featSize;
+};
+
+class CvHaarFeatureParams : public CvFeatureParams {  // haarfeatures.h:31-51
+ public:
+  enum { BASIC = 0, CORE = 1, ALL = 2 };
+  CvHaarFeatureParams() : mode(BASIC) {}
+  explicit CvHaarFeatureParams(int _mode) : mode(_mode) {}
+  void init(const CvFeatureParams& fp) override;
+  void write(cv::FileStorage& fs) const override;
+  int mode;
+};
+
+struct CvLBPFeatureParams : CvFeatureParams {  // lbpfeatures.h:22-26, lbpfeatures.cpp:9-13
+  CvLBPFeatureParams() { maxCatCount = 256; }
+};
+
+class CvFeatureEvaluator {  // traincascade_features.h:155-188
+ public:
+  CvFeatureEvaluator();
+  virtual ~CvFeatureEvaluator();
+  virtual void init(const CvFeatureParams* _featureParams, int _maxSampleCount, cv::Size _winSize);
+  virtual void setImage(const cv::Mat& img, uchar clsLabel, int idx);
+  virtual void writeFeatures(cv::FileStorage& fs, const cv::Mat& featureMap) const = 0;
+  virtual float operator()(int featureIdx, int sampleIdx) const = 0;
+  static cv::Ptr<CvFeatureEvaluator> create(int type);
+
+  int getNumFeatures() const { return numFeatures; }
+  int getMaxCatCount() const { return featureParams->maxCatCount; }
+  int getFeatureSize() const { return featureParams->featSize; }
+  const cv::Mat& getCls() const { return cls; }
+  float getCls(int si) const { return cls.at<float>(si, 0); }
+
+  // ---- batched fast paths of the MI355X implementation (what CvCascadeBoostTrainData::precalculate and
+  //      fillPassedSamples should call instead of looping over operator() / setImage) ----------------------------
+  // n images of winSize, densely packed, stored at first_idx..; labels may be NULL.
+  void setImages(const uchar* imgs, int n, int first_idx, const uchar* labels);
+  // out[(fi - fiBegin) * nSamples + s] = (*this)(fi, sampleIdx ? sampleIdx[s] : s)
+  void calcBatch(int fiBegin, int fiEnd, const int* sampleIdx, int nSamples, float* out) const;
+  cc_evaluator* handle() const { return h; }
+
+ protected:
+  virtual void generateFeatures() = 0;
+  virtual int featureType() const = 0;
+  virtual int haarMode() const { return 0; }
+  float cachedValue(int featureIdx, int sampleIdx) const;
+
+  int npos, nneg;
+  int numFeatures;
+  cv::Size winSize;
+  CvFeatureParams* featureParams;
+  cv::Mat cls;
+  cc_evaluator* h;
+  int maxSampleCount;
+  unsigned generation;  // bumped by every setImage: invalidates cached feature rows
+};
+
+class CvHaarEvaluator : public CvFeatureEvaluator {  // haarfeatures.h:61-106
+ public:
+  void init(const CvFeatureParams* _featureParams, int _maxSampleCount, cv::Size _winSize) override;
+  float operator()(int featureIdx, int sampleIdx) const override { return cachedValue(featureIdx, sampleIdx); }
+  void writeFeatures(cv::FileStorage& fs, const cv::Mat& featureMap) const override;
+  void writeFeature(cv::FileStorage& fs, int fi) const;  // for old file format
+
+  class Feature {
+   public:
+    Feature();
+    Feature(int offset, bool _tilted, int x0, int y0, int w0, int h0, float wt0, int x1, int y1, int w1, int h1, float wt1,
+            int x2 = 0, int y2 = 0, int w2 = 0, int h2 = 0, float wt2 = 0.0F);
+    // Un-normalised response on a flattened integral image held by the caller (row `y` of `sum` / `tilted`), computed
+    // on the device: the shape of the reference's Feature::calc known-answer tests (test_features.cpp:462-560).
+    float calc(const cv::Mat& sum, const cv::Mat& tilted, size_t y) const;
+    void write(cv::FileStorage& fs) const;
+    bool tilted;
+    struct {
+      cv::Rect r;
+      float weight;
+    } rect[CV_HAAR_FEATURE_MAX];
+    struct {
+      int p0, p1, p2, p3;
+    } fastRect[CV_HAAR_FEATURE_MAX];
+    int offset_;
+  };
+
+ protected:
+  void generateFeatures() override;
+  int featureType() const override { return CvFeatureParams::HAAR; }
+  int haarMode() const override;
+  Feature featureAt(int fi) const;
+};
+
+class CvLBPEvaluator : public CvFeatureEvaluator {  // lbpfeatures.h:37-68
+ public:
+  float operator()(int featureIdx, int sampleIdx) const override { return cachedValue(featureIdx, sampleIdx); }
+  void writeFeatures(cv::FileStorage& fs, const cv::Mat& featureMap) const override;
+
+ protected:
+  void generateFeatures() override;
+  int featureType() const override { return CvFeatureParams::LBP; }
+};
+
+namespace ccamd {
+
+// cv::CascadeClassifier-shaped detector (the calls tools/detection/Cpp/main.cpp:42-45 makes).
+class CascadeClassifier {
+ public:
+  CascadeClassifier();
+  explicit CascadeClassifier(const cv::String& filename, int device = 0);
+  ~CascadeClassifier();
+  CascadeClassifier(const CascadeClassifier&) = delete;
+  CascadeClassifier& operator=(const CascadeClassifier&) = delete;
+  bool load(const cv::String& filename);
+  bool empty() const { return c == nullptr; }
+  // image: CV_8UC1. Same defaults as cv::CascadeClassifier::detectMultiScale.
+  void detectMultiScale(const cv::Mat& image, std::vector<cv::Rect>& objects, double scaleFactor = 1.1, int minNeighbors = 3,
+                        int flags = 0, cv::Size minSize = cv::Size(), cv::Size maxSize = cv::Size());
+  cv::Size getOriginalWindowSize() const;
+  const std::string& lastError() const { return err; }
+
+ private:
+  cc_cascade* c;
+  cc_detector* d;
+  int device;
+  std::string err;
+};
+
+}  // namespace ccamd

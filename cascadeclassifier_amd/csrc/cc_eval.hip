@@ -234,6 +234,20 @@ __global__ __launch_bounds__(64) void k_predict(PredictArgs A) {
   A.out[s] = pass;
 }
 
+// Feature::calc on caller-held integral rows: one thread per (feature, row).
+__global__ void k_feature_calc_rows(const HaarFeatDev* __restrict__ feats, int n_feats, const int32_t* __restrict__ sum,
+                                    const int32_t* __restrict__ tilted, int n_rows, int row_len, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_feats * n_rows) return;
+  const int f = i / n_rows, r = i - f * n_rows;
+  const HaarFeatDev F = feats[f];
+  const int32_t* b = (F.tilted ? tilted : sum) + (size_t)r * row_len;
+  float ret = F.w[0] * (float)(b[F.p[0][0]] - b[F.p[0][1]] - b[F.p[0][2]] + b[F.p[0][3]]) +
+              F.w[1] * (float)(b[F.p[1][0]] - b[F.p[1][1]] - b[F.p[1][2]] + b[F.p[1][3]]);
+  if (F.w[2] != 0.0f) ret += F.w[2] * (float)(b[F.p[2][0]] - b[F.p[2][1]] - b[F.p[2][2]] + b[F.p[2][3]]);
+  out[i] = ret;
+}
+
 template <class T>
 struct EBuf {
   T* p = nullptr;
@@ -561,6 +575,54 @@ cc_status cc_eval_calc_custom_haar(cc_evaluator* e, const cc_haar_feature* feats
   if (st != CC_OK) return st;
   CC_HIP(hipMemcpyAsync(out, e->d_out.p, total * 4, hipMemcpyDeviceToHost, e->stream));
   CC_HIP(hipStreamSynchronize(e->stream));
+  return CC_OK;
+}
+
+cc_status cc_haar_feature_calc(int device, const cc_haar_feature* feats, int n_feats, int step, const int32_t* sum,
+                               const int32_t* tilted, int n_rows, int row_len, float* out) {
+  if (!feats || !out || n_feats < 0 || n_rows < 0 || row_len < 1 || step < 1) return set_error(CC_ERR_INVALID_ARG, "cc_haar_feature_calc: bad argument");
+  int ndev = 0;
+  hipError_t err = hipGetDeviceCount(&ndev);
+  if (err != hipSuccess || ndev <= 0)
+    return set_error(CC_ERR_NO_DEVICE, "no usable HIP device (%s); this library has no CPU fallback",
+                     err != hipSuccess ? hipGetErrorString(err) : "device count is 0");
+  if (device < 0 || device >= ndev) return set_error(CC_ERR_INVALID_ARG, "device %d out of range (devices: %d)", device, ndev);
+  CC_HIP(hipSetDevice(device));
+  if (n_feats == 0 || n_rows == 0) return CC_OK;
+  std::vector<HaarFeatDev> dev((size_t)n_feats);
+  bool need_sum = false, need_tilted = false;
+  for (int i = 0; i < n_feats; i++) {
+    HaarFeature f;
+    std::memcpy(f.r, feats[i].r, sizeof(f.r));
+    std::memcpy(f.w, feats[i].w, sizeof(f.w));
+    f.tilted = feats[i].tilted != 0;
+    haar_to_dev(f, step, dev[i]);
+    (f.tilted ? need_tilted : need_sum) = true;
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k < 4; k++)
+        if (dev[i].p[j][k] < 0 || dev[i].p[j][k] >= row_len)
+          return set_error(CC_ERR_OUT_OF_RANGE, "cc_haar_feature_calc: feature %d reads offset %d outside the %d-entry integral", i, dev[i].p[j][k], row_len);
+  }
+  if ((need_sum && !sum) || (need_tilted && !tilted)) return set_error(CC_ERR_INVALID_ARG, "cc_haar_feature_calc: a needed integral image is NULL");
+  EBuf<HaarFeatDev> d_f;
+  EBuf<int32_t> d_s, d_t;
+  EBuf<float> d_o;
+  const size_t nint = (size_t)n_rows * row_len, nout = (size_t)n_feats * n_rows;
+  CC_HIP(d_f.ensure((size_t)n_feats));
+  CC_HIP(hipMemcpy(d_f.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice));
+  if (sum) {
+    CC_HIP(d_s.ensure(nint));
+    CC_HIP(hipMemcpy(d_s.p, sum, nint * 4, hipMemcpyHostToDevice));
+  }
+  if (tilted) {
+    CC_HIP(d_t.ensure(nint));
+    CC_HIP(hipMemcpy(d_t.p, tilted, nint * 4, hipMemcpyHostToDevice));
+  }
+  CC_HIP(d_o.ensure(nout));
+  hipLaunchKernelGGL(k_feature_calc_rows, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, nullptr, d_f.p, n_feats, d_s.p, d_t.p,
+                     n_rows, row_len, d_o.p);
+  CC_HIP(hipGetLastError());
+  CC_HIP(hipMemcpy(out, d_o.p, nout * 4, hipMemcpyDeviceToHost));
   return CC_OK;
 }
 

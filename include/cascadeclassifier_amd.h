@@ -224,6 +224,12 @@ typedef struct cc_haar_feature {
 } cc_haar_feature;
 CC_API cc_status cc_eval_calc_custom_haar(cc_evaluator* e, const cc_haar_feature* feats, int n_feats, int normalized,
                                           const int32_t* sample_idx, int n_samples, float* out);
+/* Feature::calc (haarfeatures.h:114-122) on caller-held flattened integral images: sum / tilted are n_rows rows of
+ * row_len int32 (one integral image per row, as the reference's `sum` / `tilted` Mats; either may be NULL if no feature
+ * needs it), `step` is the integral's own row stride (window width + 1) used to form the corner offsets exactly as
+ * CV_SUM_OFFSETS / CV_TILTED_OFFSETS do. out[f * n_rows + r]. Offsets outside [0, row_len) are rejected. */
+CC_API cc_status cc_haar_feature_calc(int device, const cc_haar_feature* feats, int n_feats, int step, const int32_t* sum,
+                                      const int32_t* tilted, int n_rows, int row_len, float* out);
 /* Cached per-sample data copied back for parity tests: sum / tilted are (win_w+1)*(win_h+1) int32. */
 CC_API cc_status cc_eval_get_sample(cc_evaluator* e, int idx, int32_t* sum, int32_t* tilted, float* normfactor);
 /* Training-side cascade predict (CvCascadeClassifier::predict, cascadeclassifier.cpp:297-306 ->

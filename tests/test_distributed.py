@@ -1,0 +1,69 @@
+"""Multi-rank layer (frames shard across ranks, gather of detections only) on CPU: world_size-2 gloo processes.
+The sharding / gather code is the product's (cascadeclassifier_amd/distributed.py); per-frame detections are synthetic
+rectangle lists here, because the detection kernels need a GPU (they are covered by tests/test_gpu_detect.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from cascadeclassifier_amd.distributed import gather_detections, shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert [shard_range(512, r, 8) for r in range(8)] == [(64 * r, 64 * r + 64) for r in range(8)]  # config 4
+
+
+def _fake_detections(frame_idx):
+    rng = np.random.default_rng(1000 + frame_idx)
+    k = int(rng.integers(0, 6))
+    return rng.integers(0, 1900, (k, 4)).astype(np.int32)
+
+
+def _worker(rank, world, port, n_frames, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(n_frames, rank, world)
+    mine = [_fake_detections(f) for f in range(lo, hi)]
+    allr = gather_detections(mine)
+    q.put((rank, [a.tolist() for a in allr]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [7, 2, 1])
+def test_gather_detections_gloo_world2(n_frames):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [_fake_detections(f).tolist() for f in range(n_frames)]
+    assert got[0] == want and got[1] == want  # every rank holds all frames' detections, in global frame order
+
+
+def test_gather_is_identity_without_process_group():
+    rects = [np.array([[1, 2, 3, 4]], np.int32), np.zeros((0, 4), np.int32)]
+    out = gather_detections(rects)
+    assert len(out) == 2 and out[0].tolist() == [[1, 2, 3, 4]] and out[1].shape == (0, 4)
