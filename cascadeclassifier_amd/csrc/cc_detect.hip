@@ -15,10 +15,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
 
 #include "cc_internal.h"
 
@@ -240,6 +242,14 @@ __global__ __launch_bounds__(64) void k_integral_cols(int32_t* __restrict__ inte
     acc.w += (unsigned)v.w;
     p[(size_t)r * pitch4] = make_int4((int)acc.x, (int)acc.y, (int)acc.z, (int)acc.w);
   }
+}
+
+// Calibration stream for the FETCH_SIZE counter: same load shape as stage_tile (dword per lane, coalesced).
+__global__ __launch_bounds__(256) void k_stream_dwords(const uint32_t* __restrict__ p, size_t n_words, uint32_t* __restrict__ out) {
+  uint32_t acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) acc += p[i];
+  if (acc == 0x9e3779b9u) atomicAdd(out, acc);  // keeps the loads alive; practically never taken
+  atomicAdd(out + 1 + (threadIdx.x & 15), acc);
 }
 
 // Tilted integral from the finished upright integral (test utility and small images only: O(h) per entry).
@@ -956,6 +966,20 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
   P->n_rows = row_first[ns];
   P->n_col_blocks = col_first[ns];
   P->n_grid_rows = gridrow_first[ns];
+  // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2): permute the tile list so that the
+  // tiles one XCD receives are neighbours in the image and share their halo rows/columns in that XCD's L2.
+  // Placement only changes speed, never results.
+  {
+    const size_t n = tiles.size(), per = (n + 7) / 8;
+    std::vector<int4> perm;
+    perm.reserve(n);
+    for (size_t j = 0; j < per; j++)
+      for (size_t x = 0; x < 8; x++) {
+        const size_t src = x * per + j;
+        if (src < n) perm.push_back(tiles[src]);
+      }
+    tiles.swap(perm);
+  }
   P->n_tiles = (int)tiles.size();
   hipStream_t st = d->stream;
   CC_HIP(P->d_sd.upload(P->sd, st));
@@ -1290,23 +1314,47 @@ cc_status cc_detect_batch(cc_detector* d, const uint8_t* frames, int on_device, 
   if (st != CC_OK) return st;
   if (!offsets || (cap > 0 && !out) || cap < 0) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch: bad output buffers");
   std::vector<CandOut> cands;
+  const auto t_start = std::chrono::steady_clock::now();
   st = run_batch(d, frames, on_device, n_frames, width, height, row_stride, frame_stride, p, &cands, false);
   if (st != CC_OK) return st;
-  sort_candidates(cands);
-  size_t i = 0;
+  const auto t_dev = std::chrono::steady_clock::now();
+  // Per frame: order candidates (scale, y, x) = OpenCV's single-threaded order, then group. Frames are independent, so
+  // they are spread over a few host threads (the grouping is the only host work that scales with the batch).
+  std::vector<std::vector<CandOut>> per_frame((size_t)n_frames);
+  for (const CandOut& c : cands) per_frame[(size_t)c.frame].push_back(c);
+  std::vector<std::vector<cc_rect>> grouped((size_t)n_frames);
+  auto work = [&](int f0, int f1) {
+    for (int f = f0; f < f1; f++) {
+      sort_candidates(per_frame[(size_t)f]);
+      std::vector<cc_rect>& rects = grouped[(size_t)f];
+      rects.reserve(per_frame[(size_t)f].size());
+      for (const CandOut& c : per_frame[(size_t)f]) rects.push_back(cc_rect{c.x, c.y, c.w, c.h});
+      group_rectangles(rects, p->min_neighbors, 0.2);  // GROUP_EPS
+    }
+  };
+  const int nthr = std::max(1, std::min({n_frames, (int)std::thread::hardware_concurrency(), 16}));
+  if (nthr <= 1 || cands.size() < 2048)
+    work(0, n_frames);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthr; t++) th.emplace_back(work, (int)((long long)n_frames * t / nthr), (int)((long long)n_frames * (t + 1) / nthr));
+    for (auto& t : th) t.join();
+  }
   long long total = 0;
-  std::vector<cc_rect> rects;
   for (int f = 0; f < n_frames; f++) {
     offsets[f] = (int32_t)total;
-    rects.clear();
-    for (; i < cands.size() && cands[i].frame == f; i++) rects.push_back(cc_rect{cands[i].x, cands[i].y, cands[i].w, cands[i].h});
-    group_rectangles(rects, p->min_neighbors, 0.2);  // GROUP_EPS
-    for (const cc_rect& r : rects) {
+    for (const cc_rect& r : grouped[(size_t)f]) {
       if (total < cap) out[total] = r;
       total++;
     }
   }
   offsets[n_frames] = (int32_t)total;
+  if (std::getenv("CCAMD_TIMING")) {
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[ccamd] detect_batch: device+copy %.3f ms, sort+group %.3f ms, %zu candidates\n",
+                 std::chrono::duration<double, std::milli>(t_dev - t_start).count(),
+                 std::chrono::duration<double, std::milli>(t1 - t_dev).count(), cands.size());
+  }
   if (total > cap) return set_error(CC_ERR_BUFFER_TOO_SMALL, "cc_detect_batch: %lld rectangles, capacity %d", total, cap);
   return CC_OK;
 }
@@ -1398,6 +1446,27 @@ cc_status cc_resize_linear_exact_u8(int device, const uint8_t* src, int sw, int 
                      d_sd.p, 1, d_first.p, d_xofs.p, d_xw1.p, d_yofs.p, d_yw1.p);
   CC_HIP(hipGetLastError());
   CC_HIP(hipMemcpy2D(dst, dstride, d_dst.p, S.pitch8, dw, dh, hipMemcpyDeviceToHost));
+  return CC_OK;
+}
+
+cc_status cc_debug_stream_dwords(int device, size_t n_bytes, int repeats, uint32_t* checksum) {
+  if (n_bytes < 4 || repeats < 1) return set_error(CC_ERR_INVALID_ARG, "cc_debug_stream_dwords: bad argument");
+  cc_status st = ensure_device(device);
+  if (st != CC_OK) return st;
+  DevBuf<uint32_t> buf, out;
+  const size_t n_words = n_bytes / 4;
+  CC_HIP(buf.ensure(n_words));
+  CC_HIP(out.ensure(32));
+  CC_HIP(hipMemset(buf.p, 1, n_words * 4));
+  CC_HIP(hipMemset(out.p, 0, 32 * 4));
+  for (int r = 0; r < repeats; r++)
+    hipLaunchKernelGGL(k_stream_dwords, dim3(256 * 8), dim3(256), 0, nullptr, buf.p, n_words, out.p);
+  CC_HIP(hipGetLastError());
+  uint32_t h[32];
+  CC_HIP(hipMemcpy(h, out.p, sizeof(h), hipMemcpyDeviceToHost));
+  uint32_t c = 0;
+  for (int i = 1; i < 17; i++) c += h[i];
+  if (checksum) *checksum = c;
   return CC_OK;
 }
 

@@ -177,6 +177,10 @@ CC_API cc_status cc_integral_u8(int device, const uint8_t* img, int width, int h
                                 int32_t* sqsum, int32_t* tilted);
 CC_API cc_status cc_resize_linear_exact_u8(int device, const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst,
                                            int dw, int dh, size_t dstride);
+/* Profiling aid: streams n_bytes of device memory once with the cascade kernel's load shape (one dword per lane,
+ * 64 consecutive lanes) so that the FETCH_SIZE counter can be calibrated on a known byte count
+ * (MI355X_MICROARCH.md, HBM section). *checksum receives the wrapped 32-bit sum of the words read. */
+CC_API cc_status cc_debug_stream_dwords(int device, size_t n_bytes, int repeats, uint32_t* checksum);
 /* Host-side (tiny, serial in the reference too): cv::groupRectangles(rects, group_threshold, eps). */
 CC_API cc_status cc_group_rectangles(const cc_rect* rects, int n, int group_threshold, double eps, cc_rect* out, int cap,
                                      int* n_out);
