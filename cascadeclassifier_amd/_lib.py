@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcascadeclassifier_amd.so")
+# CCAMD_LIB selects another build of the same library (tuning experiments); the default is the in-tree build.
+LIB_PATH = os.environ.get("CCAMD_LIB") or os.path.join(_HERE, "lib", "libcascadeclassifier_amd.so")
 
 CC_OK = 0
 CC_ERR_INVALID_ARG = -1

@@ -53,8 +53,14 @@ __device__ __forceinline__ T load_record(const T CC_CONST* p) {
 }
 
 constexpr int TILE_X = 64;   // window origins per tile row = one wavefront = one rej0 mask word
-constexpr int TILE_Y = 16;   // window origin rows per tile
-constexpr int EVAL_THREADS = 512;  // 8 wavefronts share one LDS tile (more waves per LDS byte = better latency hiding)
+#ifndef CC_TILE_Y
+#define CC_TILE_Y 16  // 16 rows x 512 threads measured best (8x512: +13 %, 32x1024: +28 %, 16x1024: +50 % kernel time)
+#endif
+#ifndef CC_EVAL_THREADS
+#define CC_EVAL_THREADS 512
+#endif
+constexpr int TILE_Y = CC_TILE_Y;   // window origin rows per tile
+constexpr int EVAL_THREADS = CC_EVAL_THREADS;  // wavefronts sharing one LDS tile (more waves per LDS byte = better latency hiding)
 constexpr int EVAL_WAVES = EVAL_THREADS / 64;
 constexpr int WIN_PER_THREAD = TILE_Y / EVAL_WAVES;  // window rows per thread in the dense phase
 
@@ -305,7 +311,7 @@ struct TileGeom {
 
 constexpr int TILE_WINDOWS = TILE_X * TILE_Y;  // 1024
 constexpr int MAX_STAGES = 64;                 // per-stage queue counters live in LDS
-constexpr int PART_DOUBLES = 7 * 64;           // partial stage sums of the stump-split phase: (slices-1) x windows
+constexpr int PART_DOUBLES = (EVAL_WAVES - 1) * 64;  // partial stage sums of the stump-split phase: (slices-1) x windows
 // LDS bytes per block: integral tile (padded to 8 B) + partial sums + vnf[1024] + 2 queues of u16[1024] + counters
 __host__ __device__ inline size_t eval_lds_bytes(int tile_words) {
   return (size_t)((tile_words + 1) & ~1) * 4 + PART_DOUBLES * 8 + TILE_WINDOWS * 4 + 2 * TILE_WINDOWS * 2 + MAX_STAGES * 4;
@@ -553,7 +559,8 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
     const bool last_stage = st == A.nstages - 1;
     const int groups = (n + 63) >> 6;  // wavefronts needed to give every window a lane
     int ns = 1;                        // stump slices
-    if (A.split_stumps) ns = groups <= 1 ? 8 : groups <= 2 ? 4 : groups <= 4 ? 2 : 1;
+    if (A.split_stumps)
+      while (ns * 2 * groups <= EVAL_WAVES) ns *= 2;  // largest power of two with ns * groups <= wavefronts
     auto finish = [&](bool valid, int id, double acc) {  // whole wavefront calls
       const bool pass = valid && !(acc < thr);
       if (dbg && valid && !pass) report(id, -st, acc);
@@ -606,7 +613,7 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
         } else {
           for (int j = slice; j < nt; j += ns) acc += stump_vote(b, stumps + first + j, vnf);
         }
-        if (slice) s_part[(slice - 1) * (EVAL_THREADS / ns) + i] = acc;  // <= 7 * 64 entries for every ns
+        if (slice) s_part[(slice - 1) * (EVAL_THREADS / ns) + i] = acc;  // <= (EVAL_WAVES - 1) * 64 entries for every ns
       }
       __syncthreads();  // partial sums visible
       if (grp < groups && slice == 0) {
@@ -1253,6 +1260,11 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   d->split_stumps = exact ? 1 : 0;
   if (const char* e = std::getenv("CCAMD_SPLIT_STUMPS")) d->split_stumps = d->split_stumps && std::atoi(e) != 0;
   if (const char* e = std::getenv("CCAMD_DEBUG_STOP_AFTER_STAGE")) d->stop_after = std::atoi(e);  // timing experiments
+  if (const char* e = std::getenv("CCAMD_DEBUG_EXTRA_LDS")) {  // occupancy experiments: pad the per-block LDS request
+    d->lds += (size_t)std::max(0, std::atoi(e));
+    if (d->lds > 64 * 1024)
+      CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(haar ? &k_eval_haar : &k_eval_lbp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds));
+  }
   if (const char* e = std::getenv("CCAMD_WAVE_BELOW"))  // tuning knob; only honoured when the reduction is exact
     if (d->wave_below) d->wave_below = std::max(0, std::atoi(e));
   CC_HIP(d->d_stage_thr.upload(d->m.stage_threshold, d->stream));
