@@ -67,8 +67,8 @@ constexpr int WIN_PER_THREAD = TILE_Y / EVAL_WAVES;  // window rows per thread i
 struct ScaleDev {
   int w, h;
   int pitch8, pitchI;
-  long long img_ofs, int_ofs, mask_ofs, win_ofs;
-  int ystep, nx, ny, nxw;
+  long long img_ofs, int_ofs, mask_ofs, win_ofs, h_ofs;  // h_ofs: band-total rows of the integral builder
+  int ystep, nx, ny, nxw, nbands;
   float scale;
   int win_w, win_h;
   int xtab_ofs, ytab_ofs;
@@ -147,106 +147,140 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ fram
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: integral, row pass. One wavefront per output row (h+1 rows per scale; row 0 is zeros).
-// Writes the horizontal prefix sums of pixel row r-1 into integral row r (column c holds the sum of pixels < c),
-// for sum and (SQ) squared sum. 64 lanes x 4 pixels per step, wave scan by lane shuffles, carry across steps.
+// K2: integral images in one pass over the pixels (plus a tiny carry pass), ~10.5 B/px instead of 25 B/px for a
+// row pass + column pass. The image is cut into bands of INT_BAND rows; one wavefront owns one band of one scale and
+// walks it left to right in chunks of 256 columns (64 lanes x 4 px): per row an in-register prefix of the lane's 4 px,
+// a DPP wave scan of the lane totals and a carry into the next chunk; rows accumulate downwards in registers.
+//   k_integral_band<.., false>: only the band's column totals H[b][x] (its local integral's last row) are written;
+//   k_integral_carry          : H[b][x] <- sum of H over the bands above b (exclusive scan down the bands, in place);
+//   k_integral_band<.., true> : recomputes the band-local integral and writes row + H[b][x] (the finished integral).
+// sum and sqsum use u32 wrap-around arithmetic throughout (the detector's CV_32S squared sums).
 // ------------------------------------------------------------------------------------------------
-template <bool SQ>
-__global__ __launch_bounds__(256) void k_integral_rows(const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+constexpr int INT_BAND = 8;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+// inclusive prefix sum over the 64 lanes (row_shr 1/2/4/8 inside rows of 16, then row_bcast 15 / 31 across rows)
+__device__ __forceinline__ unsigned wave_scan_u32(unsigned v) {
+  v += dpp_u32<0x111, 0xF>(v);
+  v += dpp_u32<0x112, 0xF>(v);
+  v += dpp_u32<0x114, 0xF>(v);
+  v += dpp_u32<0x118, 0xF>(v);
+  v += dpp_u32<0x142, 0xA>(v);
+  v += dpp_u32<0x143, 0xC>(v);
+  return v;
+}
+
+template <bool SQ, bool FINAL>
+__global__ __launch_bounds__(256) void k_integral_band(const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                        int32_t* __restrict__ integ, size_t int_frame_elems, int nchan,
+                                                       int32_t* __restrict__ hbuf, size_t h_frame_elems,
                                                        const ScaleDev* __restrict__ sd, int nscales,
-                                                       const int* __restrict__ row_first, int total_rows) {
+                                                       const int* __restrict__ band_first, int total_bands) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= total_rows) return;
-  const int s = find_segment(row_first, nscales, row);
+  const int gb = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gb >= total_bands) return;
+  const int s = find_segment(band_first, nscales, gb);
   const ScaleDev S = sd[s];
-  const int r = row - row_first[s];
-  int32_t* osum = integ + ((size_t)blockIdx.y * nchan + 0) * int_frame_elems + S.int_ofs + (size_t)r * S.pitchI;
-  int32_t* osq = SQ ? integ + ((size_t)blockIdx.y * nchan + 1) * int_frame_elems + S.int_ofs + (size_t)r * S.pitchI : nullptr;
-  if (r == 0) {
-    for (int c = lane * 4; c < S.pitchI; c += 256) {
-      *reinterpret_cast<int4*>(osum + c) = make_int4(0, 0, 0, 0);
-      if (SQ) *reinterpret_cast<int4*>(osq + c) = make_int4(0, 0, 0, 0);
-    }
-    return;
-  }
-  const uint8_t* src = pyr + (size_t)blockIdx.y * pyr_frame_bytes + S.img_ofs + (size_t)(r - 1) * S.pitch8;
-  unsigned carry_s = 0, carry_q = 0;
+  const int bnd = gb - band_first[s];
+  const int r0 = bnd * INT_BAND;
+  const int nrows = min(INT_BAND, S.h - r0);
+  const size_t f = blockIdx.y;
+  const uint8_t* src = pyr + f * pyr_frame_bytes + S.img_ofs + (size_t)r0 * S.pitch8;
+  int32_t* osum = integ + (f * nchan + 0) * int_frame_elems + S.int_ofs + (size_t)(r0 + 1) * S.pitchI;
+  int32_t* osq = SQ ? integ + (f * nchan + 1) * int_frame_elems + S.int_ofs + (size_t)(r0 + 1) * S.pitchI : nullptr;
+  int32_t* hsum = hbuf + (f * nchan + 0) * h_frame_elems + S.h_ofs + (size_t)bnd * S.pitchI;
+  int32_t* hsq = SQ ? hbuf + (f * nchan + 1) * h_frame_elems + S.h_ofs + (size_t)bnd * S.pitchI : nullptr;
+  unsigned carry_s[INT_BAND], carry_q[INT_BAND];
+#pragma unroll
+  for (int r = 0; r < INT_BAND; r++) carry_s[r] = carry_q[r] = 0;
   for (int c0 = 0; c0 < S.pitchI; c0 += 256) {
     const int px = c0 + lane * 4;
-    unsigned word = 0;
-    if (px < S.pitch8) word = *reinterpret_cast<const unsigned*>(src + px);
-    unsigned p[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) p[k] = (px + k < S.w) ? ((word >> (8 * k)) & 0xffu) : 0u;
-    unsigned a[4], q[4];
-    a[0] = p[0];
-    q[0] = p[0] * p[0];
-#pragma unroll
-    for (int k = 1; k < 4; k++) {
-      a[k] = a[k - 1] + p[k];
-      q[k] = q[k - 1] + p[k] * p[k];
-    }
-    unsigned ts = a[3], tq = q[3];  // inclusive wave scan of the per-lane totals
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned us = __shfl_up(ts, d), uq = __shfl_up(tq, d);
-      if (lane >= d) {
-        ts += us;
-        if (SQ) tq += uq;
+    const bool col_ok = px < S.pitchI;
+    uint4 vs = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);  // running vertical sums of the row prefixes
+    if (FINAL && col_ok) {  // rows above this band
+      const int4 a = *reinterpret_cast<const int4*>(hsum + px);
+      vs = make_uint4((unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w);
+      if (SQ) {
+        const int4 q = *reinterpret_cast<const int4*>(hsq + px);
+        vq = make_uint4((unsigned)q.x, (unsigned)q.y, (unsigned)q.z, (unsigned)q.w);
+      }
+      if (bnd == 0) {  // integral row 0 is all zeros
+        *reinterpret_cast<int4*>(osum - S.pitchI + px) = make_int4(0, 0, 0, 0);
+        if (SQ) *reinterpret_cast<int4*>(osq - S.pitchI + px) = make_int4(0, 0, 0, 0);
       }
     }
-    const unsigned base_s = carry_s + ts - a[3], base_q = carry_q + tq - q[3];
-    const unsigned last_s = base_s + a[3], last_q = base_q + q[3];
-    unsigned prev_s = __shfl_up(last_s, 1), prev_q = __shfl_up(last_q, 1);
-    if (lane == 0) {
-      prev_s = carry_s;
-      prev_q = carry_q;
+    unsigned word[INT_BAND];
+#pragma unroll
+    for (int r = 0; r < INT_BAND; r++)
+      word[r] = (r < nrows && px < S.pitch8) ? *reinterpret_cast<const unsigned*>(src + (size_t)r * S.pitch8 + px) : 0u;
+#pragma unroll
+    for (int r = 0; r < INT_BAND; r++) {
+      unsigned p[4], a[4], q[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) p[k] = (px + k < S.w) ? ((word[r] >> (8 * k)) & 0xffu) : 0u;
+      a[0] = p[0];
+      q[0] = p[0] * p[0];
+#pragma unroll
+      for (int k = 1; k < 4; k++) {
+        a[k] = a[k - 1] + p[k];
+        q[k] = q[k - 1] + p[k] * p[k];
+      }
+      const unsigned ts = wave_scan_u32(a[3]);
+      const unsigned base_s = carry_s[r] + ts - a[3];
+      const unsigned last_s = base_s + a[3];
+      unsigned prev_s = dpp_u32<0x138, 0xF>(last_s);  // wave_shr:1: value of the previous lane
+      if (lane == 0) prev_s = carry_s[r];
+      carry_s[r] = (unsigned)__builtin_amdgcn_readlane((int)last_s, 63);
+      // column c of the integral row holds the sum of pixels < c: {prev lane's last, P0, P1, P2}
+      vs.x += prev_s;
+      vs.y += base_s + a[0];
+      vs.z += base_s + a[1];
+      vs.w += base_s + a[2];
+      if (SQ) {
+        const unsigned tq = wave_scan_u32(q[3]);
+        const unsigned base_q = carry_q[r] + tq - q[3];
+        const unsigned last_q = base_q + q[3];
+        unsigned prev_q = dpp_u32<0x138, 0xF>(last_q);
+        if (lane == 0) prev_q = carry_q[r];
+        carry_q[r] = (unsigned)__builtin_amdgcn_readlane((int)last_q, 63);
+        vq.x += prev_q;
+        vq.y += base_q + q[0];
+        vq.z += base_q + q[1];
+        vq.w += base_q + q[2];
+      }
+      if (FINAL && col_ok && r < nrows) {
+        *reinterpret_cast<int4*>(osum + (size_t)r * S.pitchI + px) = make_int4((int)vs.x, (int)vs.y, (int)vs.z, (int)vs.w);
+        if (SQ) *reinterpret_cast<int4*>(osq + (size_t)r * S.pitchI + px) = make_int4((int)vq.x, (int)vq.y, (int)vq.z, (int)vq.w);
+      }
     }
-    if (px < S.pitchI) {
-      *reinterpret_cast<int4*>(osum + px) = make_int4((int)prev_s, (int)(base_s + a[0]), (int)(base_s + a[1]), (int)(base_s + a[2]));
-      if (SQ) *reinterpret_cast<int4*>(osq + px) = make_int4((int)prev_q, (int)(base_q + q[0]), (int)(base_q + q[1]), (int)(base_q + q[2]));
+    if (!FINAL && col_ok) {
+      *reinterpret_cast<int4*>(hsum + px) = make_int4((int)vs.x, (int)vs.y, (int)vs.z, (int)vs.w);
+      if (SQ) *reinterpret_cast<int4*>(hsq + px) = make_int4((int)vq.x, (int)vq.y, (int)vq.z, (int)vq.w);
     }
-    carry_s = __shfl(last_s, 63);
-    carry_q = __shfl(last_q, 63);
   }
 }
 
-// K3: integral, column pass (in place). One thread = 4 adjacent columns of one channel of one scale; walks down the
-// rows with a running sum. Loads are issued 8 rows ahead of the dependent adds.
-__global__ __launch_bounds__(64) void k_integral_cols(int32_t* __restrict__ integ, size_t int_frame_elems, int nchan,
-                                                      const ScaleDev* __restrict__ sd, int nscales,
-                                                      const int* __restrict__ blk_first) {
+// Exclusive scan of the band totals down the bands (in place): thread = 4 adjacent columns of one channel of one scale.
+__global__ __launch_bounds__(64) void k_integral_carry(int32_t* __restrict__ hbuf, size_t h_frame_elems, int nchan,
+                                                       const ScaleDev* __restrict__ sd, int nscales,
+                                                       const int* __restrict__ blk_first) {
   const int s = find_segment(blk_first, nscales, blockIdx.x);
   const ScaleDev S = sd[s];
   const int quad = (blockIdx.x - blk_first[s]) * 64 + threadIdx.x;
   if (quad * 4 >= S.pitchI) return;
-  const int chan = blockIdx.z;
-  int4* p = reinterpret_cast<int4*>(integ + ((size_t)blockIdx.y * nchan + chan) * int_frame_elems + S.int_ofs) + quad;
+  int4* p = reinterpret_cast<int4*>(hbuf + ((size_t)blockIdx.y * nchan + blockIdx.z) * h_frame_elems + S.h_ofs) + quad;
   const size_t pitch4 = S.pitchI >> 2;
   uint4 acc = make_uint4(0, 0, 0, 0);
-  int r = 1;
-  for (; r + 8 <= S.h + 1; r += 8) {
-    int4 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = p[(size_t)(r + k) * pitch4];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      acc.x += (unsigned)v[k].x;
-      acc.y += (unsigned)v[k].y;
-      acc.z += (unsigned)v[k].z;
-      acc.w += (unsigned)v[k].w;
-      p[(size_t)(r + k) * pitch4] = make_int4((int)acc.x, (int)acc.y, (int)acc.z, (int)acc.w);
-    }
-  }
-  for (; r <= S.h; r++) {
-    const int4 v = p[(size_t)r * pitch4];
+  for (int b = 0; b < S.nbands; b++) {
+    const int4 v = p[(size_t)b * pitch4];
+    p[(size_t)b * pitch4] = make_int4((int)acc.x, (int)acc.y, (int)acc.z, (int)acc.w);
     acc.x += (unsigned)v.x;
     acc.y += (unsigned)v.y;
     acc.z += (unsigned)v.z;
     acc.w += (unsigned)v.w;
-    p[(size_t)r * pitch4] = make_int4((int)acc.x, (int)acc.y, (int)acc.z, (int)acc.w);
   }
 }
 
@@ -761,10 +795,11 @@ struct Plan {
   std::vector<ScaleDev> sd;
   size_t pyr_frame_bytes = 0, int_frame_elems = 0, mask_frame_words = 0;
   long long windows = 0, integral_elems = 0;
-  int n_resize_blocks = 0, n_rows = 0, n_col_blocks = 0, n_grid_rows = 0;
+  int n_resize_blocks = 0, n_bands = 0, n_col_blocks = 0, n_grid_rows = 0;
+  size_t h_frame_elems = 0;
   int n_tiles = 0;
   DevBuf<ScaleDev> d_sd;
-  DevBuf<int> d_resize_first, d_row_first, d_col_first, d_gridrow_first, d_xofs, d_yofs;
+  DevBuf<int> d_resize_first, d_band_first, d_col_first, d_gridrow_first, d_xofs, d_yofs;
   DevBuf<uint16_t> d_xw1, d_yw1;
   DevBuf<int4> d_tiles;
 };
@@ -795,7 +830,7 @@ struct cc_detector {
   // plans + workspace
   std::vector<std::unique_ptr<Plan>> plans;
   DevBuf<uint8_t> d_frames, d_pyr;
-  DevBuf<int32_t> d_integ;
+  DevBuf<int32_t> d_integ, d_hbuf;
   DevBuf<unsigned long long> d_masks;
   DevBuf<CandRaw> d_cands;
   DevBuf<CandOut> d_out;
@@ -919,7 +954,8 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
   P->p = p;
   scale_plan(d->m.win_w, d->m.win_h, w, h, p, P->geom);
   const int ns = (int)P->geom.size();
-  std::vector<int> resize_first(ns + 1, 0), row_first(ns + 1, 0), col_first(ns + 1, 0), gridrow_first(ns + 1, 0);
+  std::vector<int> resize_first(ns + 1, 0), band_first(ns + 1, 0), col_first(ns + 1, 0), gridrow_first(ns + 1, 0);
+  long long h_ofs = 0;
   std::vector<int> xofs, yofs;
   std::vector<uint16_t> xw1, yw1;
   std::vector<int4> tiles;
@@ -958,7 +994,10 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
     win_ofs += (long long)g.nx * g.ny;
     P->integral_elems += (long long)(g.w + 1) * (g.h + 1);
     resize_first[i + 1] = resize_first[i] + ((S.pitch8 / 4) * g.h + 255) / 256;
-    row_first[i + 1] = row_first[i] + g.h + 1;
+    S.nbands = (g.h + INT_BAND - 1) / INT_BAND;
+    S.h_ofs = h_ofs;
+    h_ofs += (long long)S.nbands * S.pitchI;
+    band_first[i + 1] = band_first[i] + S.nbands;
     col_first[i + 1] = col_first[i] + (S.pitchI / 4 + 63) / 64;
     gridrow_first[i + 1] = gridrow_first[i] + g.ny;
     const int ntx = (g.nx + TILE_X - 1) / TILE_X, nty = (g.ny + TILE_Y - 1) / TILE_Y;
@@ -970,7 +1009,8 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
   P->mask_frame_words = (size_t)mask_ofs;
   P->windows = win_ofs;
   P->n_resize_blocks = resize_first[ns];
-  P->n_rows = row_first[ns];
+  P->n_bands = band_first[ns];
+  P->h_frame_elems = (size_t)h_ofs;
   P->n_col_blocks = col_first[ns];
   P->n_grid_rows = gridrow_first[ns];
   // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2): permute the tile list so that the
@@ -991,7 +1031,7 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
   hipStream_t st = d->stream;
   CC_HIP(P->d_sd.upload(P->sd, st));
   CC_HIP(P->d_resize_first.upload(resize_first, st));
-  CC_HIP(P->d_row_first.upload(row_first, st));
+  CC_HIP(P->d_band_first.upload(band_first, st));
   CC_HIP(P->d_col_first.upload(col_first, st));
   CC_HIP(P->d_gridrow_first.upload(gridrow_first, st));
   CC_HIP(P->d_xofs.upload(xofs, st));
@@ -1044,6 +1084,26 @@ static void collect_events(cc_detector* d) {
   d->events.clear();
 }
 
+// Integral images of every scale of nf frames: band totals, carry down the bands, finished integral.
+static void launch_integral(hipStream_t st, bool sq, const uint8_t* pyr, size_t pyr_frame_bytes, int32_t* integ,
+                            size_t int_frame_elems, int nchan, int32_t* hbuf, size_t h_frame_elems, const ScaleDev* sd, int ns,
+                            const int* band_first, int n_bands, const int* col_first, int n_col_blocks, int nf) {
+  const dim3 grid((n_bands + 3) / 4, nf);
+  if (sq)
+    hipLaunchKernelGGL((k_integral_band<true, false>), grid, dim3(256), 0, st, pyr, pyr_frame_bytes, integ, int_frame_elems, nchan,
+                       hbuf, h_frame_elems, sd, ns, band_first, n_bands);
+  else
+    hipLaunchKernelGGL((k_integral_band<false, false>), grid, dim3(256), 0, st, pyr, pyr_frame_bytes, integ, int_frame_elems, nchan,
+                       hbuf, h_frame_elems, sd, ns, band_first, n_bands);
+  hipLaunchKernelGGL(k_integral_carry, dim3(n_col_blocks, nf, nchan), dim3(64), 0, st, hbuf, h_frame_elems, nchan, sd, ns, col_first);
+  if (sq)
+    hipLaunchKernelGGL((k_integral_band<true, true>), grid, dim3(256), 0, st, pyr, pyr_frame_bytes, integ, int_frame_elems, nchan,
+                       hbuf, h_frame_elems, sd, ns, band_first, n_bands);
+  else
+    hipLaunchKernelGGL((k_integral_band<false, true>), grid, dim3(256), 0, st, pyr, pyr_frame_bytes, integ, int_frame_elems, nchan,
+                       hbuf, h_frame_elems, sd, ns, band_first, n_bands);
+}
+
 // Device pipeline for up to max_batch frames already resident on the device. Leaves the filtered candidate list
 // (d_out, d_counts[1]) on the device; no synchronisation.
 static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes, int nf, size_t row_stride,
@@ -1057,6 +1117,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   if (ns == 0 || nf == 0) return CC_OK;
   CC_HIP(d->d_pyr.ensure(P->pyr_frame_bytes * (size_t)d->max_batch));
   CC_HIP(d->d_integ.ensure(P->int_frame_elems * (size_t)nchan * (size_t)d->max_batch));
+  CC_HIP(d->d_hbuf.ensure(std::max<size_t>(P->h_frame_elems * (size_t)nchan * (size_t)d->max_batch, 4)));
   CC_HIP(d->d_masks.ensure(std::max<size_t>(P->mask_frame_words * (size_t)d->max_batch, 1)));
   if (d->cand_cap == 0) d->cand_cap = 1 << 18;
   CC_HIP(d->d_cands.ensure((size_t)d->cand_cap));
@@ -1074,15 +1135,8 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   }
   {
     EvScope ev(d, EV_INTEGRAL);
-    const dim3 grid_rows((P->n_rows + 3) / 4, nf);
-    if (haar)
-      hipLaunchKernelGGL(k_integral_rows<true>, grid_rows, dim3(256), 0, st, d->d_pyr.p, P->pyr_frame_bytes, d->d_integ.p,
-                         P->int_frame_elems, nchan, P->d_sd.p, ns, P->d_row_first.p, P->n_rows);
-    else
-      hipLaunchKernelGGL(k_integral_rows<false>, grid_rows, dim3(256), 0, st, d->d_pyr.p, P->pyr_frame_bytes, d->d_integ.p,
-                         P->int_frame_elems, nchan, P->d_sd.p, ns, P->d_row_first.p, P->n_rows);
-    hipLaunchKernelGGL(k_integral_cols, dim3(P->n_col_blocks, nf, nchan), dim3(64), 0, st, d->d_integ.p, P->int_frame_elems,
-                       nchan, P->d_sd.p, ns, P->d_col_first.p);
+    launch_integral(st, haar, d->d_pyr.p, P->pyr_frame_bytes, d->d_integ.p, P->int_frame_elems, nchan, d->d_hbuf.p,
+                    P->h_frame_elems, P->d_sd.p, ns, P->d_band_first.p, P->n_bands, P->d_col_first.p, P->n_col_blocks, nf);
   }
   {
     EvScope ev(d, EV_EVAL);
@@ -1493,22 +1547,24 @@ cc_status cc_integral_u8(int device, const uint8_t* img, int width, int height, 
   S.h = height;
   S.pitch8 = align_up(width, 4);
   S.pitchI = align_up(width + 1, 4);
+  S.nbands = (height + INT_BAND - 1) / INT_BAND;
+  S.h_ofs = 0;
   std::vector<ScaleDev> sd{S};
-  std::vector<int> row_first{0, height + 1}, col_first{0, (S.pitchI / 4 + 63) / 64};
+  std::vector<int> band_first{0, S.nbands}, col_first{0, (S.pitchI / 4 + 63) / 64};
   DevBuf<ScaleDev> d_sd;
-  DevBuf<int> d_row_first, d_col_first;
+  DevBuf<int> d_band_first, d_col_first;
   DevBuf<uint8_t> d_img;
-  DevBuf<int32_t> d_int, d_tilt;
-  const size_t elems = (size_t)S.pitchI * (height + 1);
+  DevBuf<int32_t> d_int, d_h, d_tilt;
+  const size_t elems = (size_t)S.pitchI * (height + 1), helems = (size_t)S.pitchI * S.nbands;
   CC_HIP(d_sd.upload(sd, nullptr));
-  CC_HIP(d_row_first.upload(row_first, nullptr));
+  CC_HIP(d_band_first.upload(band_first, nullptr));
   CC_HIP(d_col_first.upload(col_first, nullptr));
   CC_HIP(d_img.ensure((size_t)S.pitch8 * height));
   CC_HIP(d_int.ensure(elems * 2));
+  CC_HIP(d_h.ensure(helems * 2));
   CC_HIP(hipMemcpy2D(d_img.p, S.pitch8, img, row_stride, width, height, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_integral_rows<true>, dim3((height + 1 + 3) / 4, 1), dim3(256), 0, nullptr, d_img.p, (size_t)0, d_int.p,
-                     elems, 2, d_sd.p, 1, d_row_first.p, height + 1);
-  hipLaunchKernelGGL(k_integral_cols, dim3(col_first[1], 1, 2), dim3(64), 0, nullptr, d_int.p, elems, 2, d_sd.p, 1, d_col_first.p);
+  launch_integral(nullptr, true, d_img.p, 0, d_int.p, elems, 2, d_h.p, helems, d_sd.p, 1, d_band_first.p, S.nbands, d_col_first.p,
+                  col_first[1], 1);
   CC_HIP(hipGetLastError());
   const size_t opitch = (size_t)(width + 1) * 4;
   if (sum) CC_HIP(hipMemcpy2D(sum, opitch, d_int.p, (size_t)S.pitchI * 4, opitch, height + 1, hipMemcpyDeviceToHost));
