@@ -333,8 +333,9 @@ struct TileGeom {
   __host__ __device__ TileGeom(int W0, int H0) {
     cols = (TILE_X - 1) * STEP + W0 + 1;
     rows = (TILE_Y - 1) * STEP + H0 + 1;
-    plane = STEP == 2 ? (cols + 1) / 2 : 0;
-    row_stride = STEP == 2 ? 2 * plane : cols;
+    // padded so that the 8- / 16-byte LDS stores of stage_tile stay aligned and inside the row
+    plane = STEP == 2 ? (((cols + 3) / 4 * 4) / 2 + 1) / 2 * 2 : 0;
+    row_stride = STEP == 2 ? 2 * plane : (cols + 3) / 4 * 4;
   }
   // LDS offset of integral entry (r, c) of the tile
   __host__ __device__ int at(int r, int c) const {
@@ -351,18 +352,40 @@ __host__ __device__ inline size_t eval_lds_bytes(int tile_words) {
   return (size_t)((tile_words + 1) & ~1) * 4 + PART_DOUBLES * 8 + TILE_WINDOWS * 4 + 2 * TILE_WINDOWS * 2 + MAX_STAGES * 4;
 }
 
+// Stages the tile of the integral into LDS: one wavefront per tile row, lanes = groups of 4 consecutive entries
+// (16-byte global loads; tile origins are multiples of 64 entries and row pitches multiples of 4, so they are aligned).
+// STEP 2 splits each group into its even and odd columns (two 8-byte LDS stores into the two planes).
 template <int STEP>
 __device__ __forceinline__ void stage_tile(int32_t* lds, const TileGeom<STEP>& G, const int32_t* __restrict__ sum,
                                            const ScaleDev& S, int x0, int y0) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int quads = (G.cols + 3) >> 2;
   for (int r = wave; r < G.rows; r += EVAL_WAVES) {
     const int gr = y0 + r;
     const int32_t* src = sum + (size_t)gr * S.pitchI;
-    for (int c = lane; c < G.cols; c += 64) {
-      const int gc = x0 + c;
-      int v = 0;
-      if (gr <= S.h && gc <= S.w) v = src[gc];
-      lds[G.at(r, c)] = v;
+    for (int qd = lane; qd < quads; qd += 64) {
+      const int c = qd * 4, gc = x0 + c;
+      int4 v = make_int4(0, 0, 0, 0);
+      if (gr <= S.h) {
+        if (gc + 3 < S.pitchI)
+          v = *reinterpret_cast<const int4*>(src + gc);
+        else {
+          if (gc < S.pitchI) v.x = src[gc];
+          if (gc + 1 < S.pitchI) v.y = src[gc + 1];
+          if (gc + 2 < S.pitchI) v.z = src[gc + 2];
+        }
+        if (gc > S.w) v.x = 0;  // entries right of the integral's last column read as 0
+        if (gc + 1 > S.w) v.y = 0;
+        if (gc + 2 > S.w) v.z = 0;
+        if (gc + 3 > S.w) v.w = 0;
+      }
+      if (STEP == 2) {  // c is a multiple of 4: even columns c, c+2 -> plane 0 at c/2; odd columns c+1, c+3 -> plane 1
+        int32_t* row = lds + r * G.row_stride + (c >> 1);
+        *reinterpret_cast<int2*>(row) = make_int2(v.x, v.z);
+        *reinterpret_cast<int2*>(row + G.plane) = make_int2(v.y, v.w);
+      } else {
+        *reinterpret_cast<int4*>(lds + r * G.row_stride + c) = v;
+      }
     }
   }
 }
@@ -463,6 +486,22 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
   const float CC_CONST* stage_thr = as_const_table(A.stage_thr);
   const bool dbg = A.dbg_codes != nullptr && frame == 0;
 
+  // The squared-sum integral is needed at 4 corners per window only: read them from global memory, and issue those
+  // loads before the tile is staged so that their latency hides under the staging.
+  unsigned valsq_pre[WIN_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < WIN_PER_THREAD; k++) {
+    valsq_pre[k] = 0;
+    if (HAAR) {
+      const int gx = gx0 + lane, gy = gy0 + wave * WIN_PER_THREAD + k;
+      if (gx < S.nx && gy < S.ny) {
+        const unsigned* sq = reinterpret_cast<const unsigned*>(A.integ + ((size_t)frame * A.nchan + 1) * A.int_frame_elems + S.int_ofs);
+        const int nrx = A.W0 - 2, nry = A.H0 - 2;
+        const size_t q0 = (size_t)(gy * STEP + 1) * S.pitchI + (gx * STEP + 1);
+        valsq_pre[k] = sq[q0] - sq[q0 + nrx] - sq[q0 + (size_t)nry * S.pitchI] + sq[q0 + (size_t)nry * S.pitchI + nrx];
+      }
+    }
+  }
   stage_tile<STEP>(lds, G, sum, S, gx0 * STEP, gy0 * STEP);
   if (threadIdx.x < MAX_STAGES) s_cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -504,13 +543,11 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
         const bool in_grid = alive[k];
         alive[k] = false;
         if (in_grid) {
-          const unsigned* sq = reinterpret_cast<const unsigned*>(A.integ + ((size_t)frame * A.nchan + 1) * A.int_frame_elems + S.int_ofs);
           const int nrx = A.W0 - 2, nry = A.H0 - 2;
           const double area = (double)(nrx * nry);
           const int32_t* b = lds + base[k];
           const int valsum = b[G.at(1, 1)] - b[G.at(1, 1 + nrx)] - b[G.at(1 + nry, 1)] + b[G.at(1 + nry, 1 + nrx)];
-          const size_t q0 = (size_t)(gy * STEP + 1) * S.pitchI + (gx * STEP + 1);
-          const unsigned valsq = sq[q0] - sq[q0 + nrx] - sq[q0 + (size_t)nry * S.pitchI] + sq[q0 + (size_t)nry * S.pitchI + nrx];
+          const unsigned valsq = valsq_pre[k];
           double nf = area * (double)valsq - (double)valsum * (double)valsum;
           if (nf > 0.) {
             nf = sqrt(nf);
