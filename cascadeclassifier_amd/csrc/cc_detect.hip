@@ -870,8 +870,12 @@ struct cc_detector {
   DevBuf<int32_t> d_integ, d_hbuf;
   DevBuf<unsigned long long> d_masks;
   DevBuf<CandRaw> d_cands;
-  DevBuf<CandOut> d_out;
-  DevBuf<int> d_counts;  // [0] raw count, [1] filtered count
+  // Results of a pass are double-buffered so that the host can fetch and group pass i while the device runs pass i+1.
+  DevBuf<CandOut> d_out[2];
+  DevBuf<int> d_counts[2];  // [0] raw count, [1] filtered count
+  int* h_counts = nullptr;  // pinned, 2 x 2 ints
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t pass_done[2] = {nullptr, nullptr};
   int cand_cap = 0;
   DevBuf<int32_t> d_dbg_codes;
   DevBuf<double> d_dbg_sums;
@@ -887,6 +891,10 @@ struct cc_detector {
       (void)hipEventDestroy(e.b);
     }
     if (own_stream) (void)hipStreamDestroy(own_stream);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    for (auto& e : pass_done)
+      if (e) (void)hipEventDestroy(e);
+    if (h_counts) (void)hipHostFree(h_counts);
   }
 };
 
@@ -1142,15 +1150,15 @@ static void launch_integral(hipStream_t st, bool sq, const uint8_t* pyr, size_t 
 }
 
 // Device pipeline for up to max_batch frames already resident on the device. Leaves the filtered candidate list
-// (d_out, d_counts[1]) on the device; no synchronisation.
+// (d_out[slot], d_counts[slot][1]) on the device; no synchronisation.
 static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes, int nf, size_t row_stride,
-                                 size_t frame_stride, bool debug) {
+                                 size_t frame_stride, bool debug, int slot) {
   const int ns = (int)P->sd.size();
   hipStream_t st = d->stream;
   const bool haar = d->m.feature_type == CC_FEATURE_HAAR;
   const int nchan = haar ? 2 : 1;
-  CC_HIP(d->d_counts.ensure(2));
-  CC_HIP(hipMemsetAsync(d->d_counts.p, 0, 2 * sizeof(int), st));
+  CC_HIP(d->d_counts[slot].ensure(2));
+  CC_HIP(hipMemsetAsync(d->d_counts[slot].p, 0, 2 * sizeof(int), st));
   if (ns == 0 || nf == 0) return CC_OK;
   CC_HIP(d->d_pyr.ensure(P->pyr_frame_bytes * (size_t)d->max_batch));
   CC_HIP(d->d_integ.ensure(P->int_frame_elems * (size_t)nchan * (size_t)d->max_batch));
@@ -1158,7 +1166,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   CC_HIP(d->d_masks.ensure(std::max<size_t>(P->mask_frame_words * (size_t)d->max_batch, 1)));
   if (d->cand_cap == 0) d->cand_cap = 1 << 18;
   CC_HIP(d->d_cands.ensure((size_t)d->cand_cap));
-  CC_HIP(d->d_out.ensure((size_t)d->cand_cap));
+  CC_HIP(d->d_out[slot].ensure((size_t)d->cand_cap));
   if (debug) {
     CC_HIP(d->d_dbg_codes.ensure((size_t)std::max<long long>(P->windows, 1)));
     CC_HIP(d->d_dbg_sums.ensure((size_t)std::max<long long>(P->windows, 1)));
@@ -1194,7 +1202,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.masks = d->d_masks.p;
     A.mask_frame_words = P->mask_frame_words;
     A.cands = d->d_cands.p;
-    A.cand_count = d->d_counts.p;
+    A.cand_count = d->d_counts[slot].p;
     A.cand_cap = d->cand_cap;
     A.dbg_codes = debug ? d->d_dbg_codes.p : nullptr;
     A.dbg_sums = debug ? d->d_dbg_sums.p : nullptr;
@@ -1210,8 +1218,8 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   }
   {
     EvScope ev(d, EV_FILTER);
-    hipLaunchKernelGGL(k_filter_candidates, dim3(64), dim3(256), 0, st, d->d_cands.p, d->d_counts.p, d->cand_cap, P->d_sd.p,
-                       d->d_masks.p, P->mask_frame_words, d->d_out.p, d->d_counts.p + 1);
+    hipLaunchKernelGGL(k_filter_candidates, dim3(64), dim3(256), 0, st, d->d_cands.p, d->d_counts[slot].p, d->cand_cap, P->d_sd.p,
+                       d->d_masks.p, P->mask_frame_words, d->d_out[slot].p, d->d_counts[slot].p + 1);
     if (debug && P->n_grid_rows)
       hipLaunchKernelGGL(k_debug_visited, dim3(P->n_grid_rows), dim3(256), 0, st, P->d_sd.p, ns, P->d_gridrow_first.p,
                          d->d_masks.p, d->d_dbg_visited.p);
@@ -1233,54 +1241,103 @@ static cc_status check_frame_args(const cc_detector* d, const uint8_t* frames, i
   return CC_OK;
 }
 
-// Runs the batch in passes of max_batch frames. If collect != nullptr the filtered candidates of every pass are
-// copied back and appended (frame index made global).
+// Runs the batch in passes. `consume` (optional) receives the filtered candidates of each pass (frame indices made
+// global) on the calling thread. With two or more frames the batch is cut into at least two passes and the host side
+// of pass i (copy-back + consume) overlaps the device side of pass i+1.
+template <class Consume>
 static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device, int n_frames, int width, int height,
-                           size_t row_stride, size_t frame_stride, const cc_detect_params* p, std::vector<CandOut>* collect,
-                           bool debug) {
+                           size_t row_stride, size_t frame_stride, const cc_detect_params* p, bool want_results, bool debug,
+                           Consume consume) {
   cc_status stt = ensure_device(d->device);
   if (stt != CC_OK) return stt;
   Plan* P = nullptr;
   stt = build_plan(d, width, height, *p, &P);
   if (stt != CC_OK) return stt;
-  for (int f0 = 0; f0 < n_frames; f0 += d->max_batch) {
-    const int nf = std::min(d->max_batch, n_frames - f0);
+  if (!d->copy_stream) {
+    CC_HIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+    CC_HIP(hipEventCreateWithFlags(&d->pass_done[0], hipEventDisableTiming));
+    CC_HIP(hipEventCreateWithFlags(&d->pass_done[1], hipEventDisableTiming));
+    CC_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->h_counts), 4 * sizeof(int), hipHostMallocDefault));
+  }
+  int pass_frames = d->max_batch;
+  if (want_results && n_frames >= 2) {  // only the last pass's host work is exposed: use a few passes, not two halves
+    int passes = 4;
+    if (const char* e = std::getenv("CCAMD_PIPELINE_PASSES")) passes = std::max(1, std::atoi(e));
+    passes = std::min(passes, n_frames);
+    pass_frames = std::min(d->max_batch, (n_frames + passes - 1) / passes);
+  }
+  struct Pass {
+    int f0, nf, slot;
     const uint8_t* dptr;
-    size_t rs = row_stride, fs = frame_stride;
-    if (on_device) {
-      dptr = frames + (size_t)f0 * frame_stride;
-    } else {
-      rs = (size_t)align_up(width, 4);
-      fs = rs * (size_t)height;
-      CC_HIP(d->d_frames.ensure(fs * (size_t)d->max_batch));
-      for (int f = 0; f < nf; f++)
-        CC_HIP(hipMemcpy2DAsync(d->d_frames.p + (size_t)f * fs, rs, frames + (size_t)(f0 + f) * frame_stride, row_stride,
-                                (size_t)width, (size_t)height, hipMemcpyHostToDevice, d->stream));
-      dptr = d->d_frames.p;
-    }
+    size_t rs, fs;
+  };
+  std::vector<CandOut> got;
+  // fetches the results of a launched pass; on candidate-list overflow grows the lists and redoes the pass synchronously
+  auto retire = [&](const Pass& ps) -> cc_status {
     for (;;) {
-      stt = run_device_pass(d, P, dptr, nf, rs, fs, debug);
-      if (stt != CC_OK) return stt;
-      if (!collect) break;
-      int counts[2] = {0, 0};
-      CC_HIP(hipMemcpyAsync(counts, d->d_counts.p, sizeof(counts), hipMemcpyDeviceToHost, d->stream));
-      CC_HIP(hipStreamSynchronize(d->stream));
-      if (counts[0] > d->cand_cap) {  // candidate list overflowed: grow and redo this pass
-        d->cand_cap = counts[0] + counts[0] / 2;
+      CC_HIP(hipEventSynchronize(d->pass_done[ps.slot]));
+      const int raw = d->h_counts[2 * ps.slot], kept = d->h_counts[2 * ps.slot + 1];
+      if (raw > d->cand_cap) {
+        CC_HIP(hipStreamSynchronize(d->stream));
+        d->cand_cap = raw + raw / 2;
         d->d_cands.release();
-        d->d_out.release();
+        d->d_out[0].release();
+        d->d_out[1].release();
+        cc_status st2 = run_device_pass(d, P, ps.dptr, ps.nf, ps.rs, ps.fs, debug, ps.slot);
+        if (st2 != CC_OK) return st2;
+        CC_HIP(hipMemcpyAsync(d->h_counts + 2 * ps.slot, d->d_counts[ps.slot].p, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+        CC_HIP(hipEventRecord(d->pass_done[ps.slot], d->stream));
         continue;
       }
-      const size_t o = collect->size();
-      collect->resize(o + (size_t)counts[1]);
-      if (counts[1] > 0) {
-        CC_HIP(hipMemcpyAsync(collect->data() + o, d->d_out.p, (size_t)counts[1] * sizeof(CandOut), hipMemcpyDeviceToHost,
-                              d->stream));
-        CC_HIP(hipStreamSynchronize(d->stream));
-        for (size_t i = o; i < collect->size(); i++) (*collect)[i].frame += f0;
+      got.resize((size_t)kept);
+      if (kept > 0) {  // the copy stream is free to run while the main stream executes the next pass
+        CC_HIP(hipMemcpyAsync(got.data(), d->d_out[ps.slot].p, (size_t)kept * sizeof(CandOut), hipMemcpyDeviceToHost, d->copy_stream));
+        CC_HIP(hipStreamSynchronize(d->copy_stream));
+        for (CandOut& c : got) c.frame += ps.f0;
       }
-      break;
+      consume(ps.f0, ps.nf, got);
+      return CC_OK;
     }
+  };
+  Pass prev{};
+  bool have_prev = false;
+  int slot = 0;
+  for (int f0 = 0; f0 < n_frames; f0 += pass_frames) {
+    Pass ps;
+    ps.f0 = f0;
+    ps.nf = std::min(pass_frames, n_frames - f0);
+    ps.slot = slot;
+    ps.rs = row_stride;
+    ps.fs = frame_stride;
+    if (on_device) {
+      ps.dptr = frames + (size_t)f0 * frame_stride;
+    } else {  // staging area is double-buffered like the results
+      ps.rs = (size_t)align_up(width, 4);
+      ps.fs = ps.rs * (size_t)height;
+      CC_HIP(d->d_frames.ensure(ps.fs * (size_t)d->max_batch * 2));
+      uint8_t* stage = d->d_frames.p + (size_t)slot * ps.fs * (size_t)d->max_batch;
+      for (int f = 0; f < ps.nf; f++)
+        CC_HIP(hipMemcpy2DAsync(stage + (size_t)f * ps.fs, ps.rs, frames + (size_t)(f0 + f) * frame_stride, row_stride,
+                                (size_t)width, (size_t)height, hipMemcpyHostToDevice, d->stream));
+      ps.dptr = stage;
+    }
+    stt = run_device_pass(d, P, ps.dptr, ps.nf, ps.rs, ps.fs, debug, slot);
+    if (stt != CC_OK) return stt;
+    if (want_results) {
+      CC_HIP(hipMemcpyAsync(d->h_counts + 2 * slot, d->d_counts[slot].p, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+      CC_HIP(hipEventRecord(d->pass_done[slot], d->stream));
+      if (have_prev) {
+        stt = retire(prev);
+        if (stt != CC_OK) return stt;
+      }
+      prev = ps;
+      have_prev = true;
+      slot ^= 1;
+    }
+  }
+  if (have_prev) {
+    stt = retire(prev);
+    if (stt != CC_OK) return stt;
   }
   if (d->profiling) {
     CC_HIP(hipStreamSynchronize(d->stream));
@@ -1407,7 +1464,8 @@ cc_status cc_detect_batch_device_only(cc_detector* d, const uint8_t* frames, int
                                       size_t row_stride, size_t frame_stride, const cc_detect_params* p) {
   cc_status st = check_frame_args(d, frames, n_frames, width, height, row_stride, p, "cc_detect_batch_device_only");
   if (st != CC_OK) return st;
-  return run_batch(d, frames, on_device, n_frames, width, height, row_stride, frame_stride, p, nullptr, false);
+  return run_batch(d, frames, on_device, n_frames, width, height, row_stride, frame_stride, p, false, false,
+                   [](int, int, std::vector<CandOut>&) {});
 }
 
 cc_status cc_detect_batch(cc_detector* d, const uint8_t* frames, int on_device, int n_frames, int width, int height,
@@ -1416,33 +1474,38 @@ cc_status cc_detect_batch(cc_detector* d, const uint8_t* frames, int on_device, 
   cc_status st = check_frame_args(d, frames, n_frames, width, height, row_stride, p, "cc_detect_batch");
   if (st != CC_OK) return st;
   if (!offsets || (cap > 0 && !out) || cap < 0) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch: bad output buffers");
-  std::vector<CandOut> cands;
   const auto t_start = std::chrono::steady_clock::now();
-  st = run_batch(d, frames, on_device, n_frames, width, height, row_stride, frame_stride, p, &cands, false);
-  if (st != CC_OK) return st;
-  const auto t_dev = std::chrono::steady_clock::now();
-  // Per frame: order candidates (scale, y, x) = OpenCV's single-threaded order, then group. Frames are independent, so
-  // they are spread over a few host threads (the grouping is the only host work that scales with the batch).
-  std::vector<std::vector<CandOut>> per_frame((size_t)n_frames);
-  for (const CandOut& c : cands) per_frame[(size_t)c.frame].push_back(c);
+  double group_ms = 0;
+  size_t n_cands = 0;
   std::vector<std::vector<cc_rect>> grouped((size_t)n_frames);
-  auto work = [&](int f0, int f1) {
-    for (int f = f0; f < f1; f++) {
-      sort_candidates(per_frame[(size_t)f]);
-      std::vector<cc_rect>& rects = grouped[(size_t)f];
-      rects.reserve(per_frame[(size_t)f].size());
-      for (const CandOut& c : per_frame[(size_t)f]) rects.push_back(cc_rect{c.x, c.y, c.w, c.h});
-      group_rectangles(rects, p->min_neighbors, 0.2);  // GROUP_EPS
+  // Called once per pass, while the device already runs the next pass. Per frame: order candidates (scale, y, x) =
+  // OpenCV's single-threaded order, then group. Frames are independent, so they are spread over a few host threads.
+  auto consume = [&](int f0, int nf, std::vector<CandOut>& cands) {
+    const auto t0 = std::chrono::steady_clock::now();
+    n_cands += cands.size();
+    std::vector<std::vector<CandOut>> per_frame((size_t)nf);
+    for (const CandOut& c : cands) per_frame[(size_t)(c.frame - f0)].push_back(c);
+    auto work = [&](int a0, int a1) {
+      for (int f = a0; f < a1; f++) {
+        sort_candidates(per_frame[(size_t)f]);
+        std::vector<cc_rect>& rects = grouped[(size_t)(f0 + f)];
+        rects.reserve(per_frame[(size_t)f].size());
+        for (const CandOut& c : per_frame[(size_t)f]) rects.push_back(cc_rect{c.x, c.y, c.w, c.h});
+        group_rectangles(rects, p->min_neighbors, 0.2);  // GROUP_EPS
+      }
+    };
+    const int nthr = std::max(1, std::min({nf, (int)std::thread::hardware_concurrency(), 16}));
+    if (nthr <= 1 || cands.size() < 2048)
+      work(0, nf);
+    else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthr; t++) th.emplace_back(work, (int)((long long)nf * t / nthr), (int)((long long)nf * (t + 1) / nthr));
+      for (auto& t : th) t.join();
     }
+    group_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
-  const int nthr = std::max(1, std::min({n_frames, (int)std::thread::hardware_concurrency(), 16}));
-  if (nthr <= 1 || cands.size() < 2048)
-    work(0, n_frames);
-  else {
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthr; t++) th.emplace_back(work, (int)((long long)n_frames * t / nthr), (int)((long long)n_frames * (t + 1) / nthr));
-    for (auto& t : th) t.join();
-  }
+  st = run_batch(d, frames, on_device, n_frames, width, height, row_stride, frame_stride, p, true, false, consume);
+  if (st != CC_OK) return st;
   long long total = 0;
   for (int f = 0; f < n_frames; f++) {
     offsets[f] = (int32_t)total;
@@ -1454,9 +1517,8 @@ cc_status cc_detect_batch(cc_detector* d, const uint8_t* frames, int on_device, 
   offsets[n_frames] = (int32_t)total;
   if (std::getenv("CCAMD_TIMING")) {
     const auto t1 = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[ccamd] detect_batch: device+copy %.3f ms, sort+group %.3f ms, %zu candidates\n",
-                 std::chrono::duration<double, std::milli>(t_dev - t_start).count(),
-                 std::chrono::duration<double, std::milli>(t1 - t_dev).count(), cands.size());
+    std::fprintf(stderr, "[ccamd] detect_batch: total %.3f ms, of which sort+group on the host %.3f ms (overlapped), %zu candidates\n",
+                 std::chrono::duration<double, std::milli>(t1 - t_start).count(), group_ms, n_cands);
   }
   if (total > cap) return set_error(CC_ERR_BUFFER_TOO_SMALL, "cc_detect_batch: %lld rectangles, capacity %d", total, cap);
   return CC_OK;
@@ -1477,7 +1539,8 @@ cc_status cc_detect_raw(cc_detector* d, const uint8_t* gray, int width, int heig
   if (st != CC_OK) return st;
   if (!n || (cap > 0 && !cand)) return set_error(CC_ERR_INVALID_ARG, "cc_detect_raw: bad output buffers");
   std::vector<CandOut> cands;
-  st = run_batch(d, gray, 0, 1, width, height, row_stride, row_stride * (size_t)height, p, &cands, false);
+  st = run_batch(d, gray, 0, 1, width, height, row_stride, row_stride * (size_t)height, p, true, false,
+                 [&](int, int, std::vector<CandOut>& c) { cands.insert(cands.end(), c.begin(), c.end()); });
   if (st != CC_OK) return st;
   sort_candidates(cands);
   *n = (int)cands.size();
@@ -1497,7 +1560,8 @@ cc_status cc_detect_debug_windows(cc_detector* d, const uint8_t* gray, int width
   if (st != CC_OK) return st;
   if (!n_windows) return set_error(CC_ERR_INVALID_ARG, "cc_detect_debug_windows: null count pointer");
   std::vector<CandOut> cands;
-  st = run_batch(d, gray, 0, 1, width, height, row_stride, row_stride * (size_t)height, p, &cands, true);
+  st = run_batch(d, gray, 0, 1, width, height, row_stride, row_stride * (size_t)height, p, true, true,
+                 [&](int, int, std::vector<CandOut>& c) { cands.insert(cands.end(), c.begin(), c.end()); });
   if (st != CC_OK) return st;
   Plan* P = nullptr;
   st = build_plan(d, width, height, *p, &P);
