@@ -128,14 +128,17 @@ def main():
 
     total_windows = windows_per_frame * B * world * args.steps
     value = total_windows / dt / 1e6
-    eval_ms = tm["eval_ms"] / max(tm["eval_launches"], 1)  # average duration of one launch (HIP events on the detector's stream)
-    ach = eval_bytes_per_frame * B / (eval_ms * 1e-3) / 1e9 if eval_ms > 0 else 0.0
+    # average duration of one launch of the cascade kernel (HIP events on the detector's stream) and the frames one
+    # launch covers (a step is cut into a few pipelined passes, one launch each)
+    eval_ms = tm["eval_ms"] / max(tm["eval_launches"], 1)
+    frames_per_launch = tm["frames"] / max(tm["eval_launches"], 1)
+    ach = eval_bytes_per_frame * frames_per_launch / (eval_ms * 1e-3) / 1e9 if eval_ms > 0 else 0.0
     # HBM traffic of the cascade kernel comes from PMC counters, which need their own rocprofv3 passes
     # (tools/profile_bench.sh); the committed measurement is scaled to this run's frames per launch.
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "r01_traffic_k_eval_haar.json")
     if inf["feature_type"] == 0 and os.path.exists(tfile) and (W, H) == (1920, 1080) and abs(args.scale_factor - 1.1) < 1e-12:
-        traffic = round(json.load(open(tfile))["hbm_bytes_per_frame"] * B)
+        traffic = round(json.load(open(tfile))["hbm_bytes_per_frame"] * frames_per_launch)
     out = {
         "metric": "detection Mwindows/sec (1080p, haarcascade_frontalface) + achieved HBM GB/s",
         "value": round(value, 3),
@@ -171,7 +174,8 @@ def main():
             "traffic": traffic,
             "traffic_source": "profiles/r01_traffic_k_eval_haar.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH x2 gfx950 correction, "
                               "calibrated with tools/calibrate_fetch.py)" if traffic else None,
-            "algorithmic_bytes_per_launch": eval_bytes_per_frame * B,
+            "algorithmic_bytes_per_launch": round(eval_bytes_per_frame * frames_per_launch),
+            "frames_per_launch": frames_per_launch,
             "avg_launch_ms": round(eval_ms, 4),
         },
     }

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(64) void k_set_images(const uint8_t* __restrict__ i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Bulk operator(): block = 256 threads, a tile of S samples staged transposed into LDS, loops over a feature chunk.
+// Bulk operator(): block = BATCH_THREADS threads, a tile of S samples staged transposed into LDS, loops over a feature chunk.
 // lane -> (feature sub-index, sample): s = lane % S.
 // ------------------------------------------------------------------------------------------------
 struct BatchArgs {
@@ -115,19 +116,22 @@ struct BatchArgs {
   int feats_per_block;
   const void* feats;
   float* out;                 // [feat_end - feat_begin][n_samples]
+  int debug_nostore;          // timing experiment: skip the output stores
   int normalized;             // Haar: divide by normfactor (operator()) or not (Feature::calc)
   int use_tilted;
 };
 
+constexpr int BATCH_THREADS = 1024;  // 16 wavefronts per block: the LDS tile allows two blocks per CU = full occupancy
+
 template <bool HAAR>
-__global__ __launch_bounds__(256) void k_eval_batch(BatchArgs A) {
+__global__ __launch_bounds__(BATCH_THREADS) void k_eval_batch(BatchArgs A) {
   extern __shared__ int32_t lds[];  // [cols][S] (+ [cols][S] tilted)
   const int S = A.S;
   const int s0 = blockIdx.x * S;
   int32_t* lsum = lds;
   int32_t* ltil = lds + (size_t)A.cols * S;
   // stage: consecutive threads read consecutive entries of one sample (coalesced), write transposed
-  for (int e = threadIdx.x; e < A.cols * S; e += 256) {
+  for (int e = threadIdx.x; e < A.cols * S; e += BATCH_THREADS) {
     const int s = e / A.cols, p = e - s * A.cols;
     int v = 0, t = 0;
     if (s0 + s < A.n_samples) {
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) void k_eval_batch(BatchArgs A) {
   }
   __syncthreads();
   const int s = threadIdx.x % S;
-  const int fsub = threadIdx.x / S, fpar = 256 / S;
+  const int fsub = threadIdx.x / S, fpar = BATCH_THREADS / S;
   const bool valid = s0 + s < A.n_samples;
   float nf = 1.f;
   if (HAAR && A.normalized && valid) nf = A.normfactor[A.sample_idx ? A.sample_idx[s0 + s] : s0 + s];
@@ -151,17 +155,16 @@ __global__ __launch_bounds__(256) void k_eval_batch(BatchArgs A) {
     if (HAAR) {
       const HaarFeatDev F = reinterpret_cast<const HaarFeatDev*>(A.feats)[f];
       const int32_t* img = (F.tilted ? ltil : lsum) + s;
-      float ret = F.w[0] * (float)(img[F.p[0][0] * S] - img[F.p[0][1] * S] - img[F.p[0][2] * S] + img[F.p[0][3] * S]) +
-                  F.w[1] * (float)(img[F.p[1][0] * S] - img[F.p[1][1] * S] - img[F.p[1][2] * S] + img[F.p[1][3] * S]);
-      if (F.w[2] != 0.0f)
-        ret += F.w[2] * (float)(img[F.p[2][0] * S] - img[F.p[2][1] * S] - img[F.p[2][2] * S] + img[F.p[2][3] * S]);
+      float ret = F.w[0] * (float)(img[F.p[0][0]] - img[F.p[0][1]] - img[F.p[0][2]] + img[F.p[0][3]]) +
+                  F.w[1] * (float)(img[F.p[1][0]] - img[F.p[1][1]] - img[F.p[1][2]] + img[F.p[1][3]]);
+      if (F.w[2] != 0.0f) ret += F.w[2] * (float)(img[F.p[2][0]] - img[F.p[2][1]] - img[F.p[2][2]] + img[F.p[2][3]]);
       val = A.normalized ? (nf == 0.0f ? 0.0f : ret / nf) : ret;
     } else {
       const LbpFeatDev F = reinterpret_cast<const LbpFeatDev*>(A.feats)[f];
       const int32_t* b = lsum + s;
       int p[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) p[j] = b[F.p[j] * S];
+      for (int j = 0; j < 16; j++) p[j] = b[F.p[j]];
       const int c = p[5] - p[6] - p[9] + p[10];
       const int code = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
                        (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void k_eval_batch(BatchArgs A) {
                        (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
       val = (float)code;
     }
-    if (valid) A.out[(size_t)(f - A.feat_begin) * A.n_samples + s0 + s] = val;
+    if (valid && (!A.debug_nostore || val == 12345.678f)) A.out[(size_t)(f - A.feat_begin) * A.n_samples + s0 + s] = val;
   }
 }
 
@@ -266,7 +269,8 @@ struct EBuf {
   }
 };
 
-static void haar_to_dev(const HaarFeature& f, int step, HaarFeatDev& d) {
+// `mul` scales the offsets (the batch kernel's LDS tile is [entry][S samples]: entry offsets are pre-multiplied by S).
+static void haar_to_dev(const HaarFeature& f, int step, HaarFeatDev& d, int mul = 1) {
   std::memset(&d, 0, sizeof(d));
   d.tilted = f.tilted;
   for (int j = 0; j < 3; j++) d.w[j] = f.w[j];
@@ -284,12 +288,13 @@ static void haar_to_dev(const HaarFeature& f, int step, HaarFeatDev& d) {
       d.p[j][2] = x + w + step * (y + w);
       d.p[j][3] = x + w - h + step * (y + w + h);
     }
+    for (int k = 0; k < 4; k++) d.p[j][k] *= mul;
   }
 }
 
-static void lbp_to_dev(const int32_t* r, int step, LbpFeatDev& d) {  // lbpfeatures.cpp:53-63
+static void lbp_to_dev(const int32_t* r, int step, LbpFeatDev& d, int mul = 1) {  // lbpfeatures.cpp:53-63
   for (int rr = 0; rr < 4; rr++)
-    for (int cc = 0; cc < 4; cc++) d.p[4 * rr + cc] = (r[0] + cc * r[2]) + step * (r[1] + rr * r[3]);
+    for (int cc = 0; cc < 4; cc++) d.p[4 * rr + cc] = ((r[0] + cc * r[2]) + step * (r[1] + rr * r[3])) * mul;
 }
 
 }  // namespace ccamd
@@ -354,19 +359,20 @@ static cc_status launch_batch(cc_evaluator* e, bool haar, const void* feats, int
   A.feats = feats;
   A.out = d_out_ptr;
   A.normalized = normalized;
+  A.debug_nostore = std::getenv("CCAMD_DEBUG_EVAL_NOSTORE") ? 1 : 0;
   A.use_tilted = e->use_tilted ? 1 : 0;
   const int nfe = fe - fb;
   const int tiles = (ns + e->S - 1) / e->S;
-  // enough feature chunks to fill the chip, but each block amortises its tile load over >= 512 features
-  int chunks = std::max(1, std::min((nfe + 511) / 512, std::max(1, 8192 / std::max(tiles, 1))));
+  // enough feature chunks to fill the chip, but each block amortises its tile load over >= 2048 features
+  int chunks = std::max(1, std::min((nfe + 2047) / 2048, std::max(1, 16384 / std::max(tiles, 1))));
   A.feats_per_block = (nfe + chunks - 1) / chunks;
   chunks = (nfe + A.feats_per_block - 1) / A.feats_per_block;
   const size_t lds = (size_t)e->cols * e->S * 4 * (haar && e->use_tilted ? 2 : 1);
   (void)hipEventRecord(e->ev_a, e->stream);
   if (haar)
-    hipLaunchKernelGGL(k_eval_batch<true>, dim3(tiles, chunks), dim3(256), lds, e->stream, A);
+    hipLaunchKernelGGL(k_eval_batch<true>, dim3(tiles, chunks), dim3(BATCH_THREADS), lds, e->stream, A);
   else
-    hipLaunchKernelGGL(k_eval_batch<false>, dim3(tiles, chunks), dim3(256), lds, e->stream, A);
+    hipLaunchKernelGGL(k_eval_batch<false>, dim3(tiles, chunks), dim3(BATCH_THREADS), lds, e->stream, A);
   (void)hipEventRecord(e->ev_b, e->stream);
   CC_HIP(hipGetLastError());
   return CC_OK;
@@ -412,12 +418,19 @@ cc_status cc_eval_create(int feature_type, int haar_mode, int win_w, int win_h, 
   cc_status st = eval_device(e.get());
   if (st != CC_OK) return st;
   e->cls.assign((size_t)max_samples, 0.f);
-  // samples per LDS tile: largest power of two that keeps the tile within 64 KiB
+  // samples per LDS tile: largest power of two (<= 32) that keeps the tile within 80 KB (two blocks per CU). With 32
+  // samples per tile each 32-lane half of a wavefront is one feature over 32 consecutive samples: LDS reads are
+  // conflict-free and every output store is a full 128-byte line.
   const size_t per_sample = (size_t)e->cols * 4 * (e->use_tilted ? 2 : 1);
-  int S = 64;
-  while (S > 1 && per_sample * S > 64 * 1024) S >>= 1;
-  if (per_sample * S > 64 * 1024) return set_error(CC_ERR_UNSUPPORTED, "cc_eval_create: window %dx%d too large for the LDS tile", win_w, win_h);
+  const size_t budget = 80 * 1024;
+  int S = 32;
+  while (S > 1 && per_sample * S > budget) S >>= 1;
+  if (per_sample * S > budget) return set_error(CC_ERR_UNSUPPORTED, "cc_eval_create: window %dx%d too large for the LDS tile", win_w, win_h);
   e->S = S;
+  if (per_sample * S > 64 * 1024) {
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_batch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_sample * S)));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_sample * S)));
+  }
   CC_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   CC_HIP(hipEventCreate(&e->ev_a));
   CC_HIP(hipEventCreate(&e->ev_b));
@@ -433,14 +446,14 @@ cc_status cc_eval_create(int feature_type, int haar_mode, int win_w, int win_h, 
     haar_catalog(win_w, win_h, haar_mode, e->haar);
     e->nfeat = (int)e->haar.size();
     std::vector<HaarFeatDev> dev(e->haar.size());
-    for (size_t i = 0; i < dev.size(); i++) haar_to_dev(e->haar[i], win_w + 1, dev[i]);
+    for (size_t i = 0; i < dev.size(); i++) haar_to_dev(e->haar[i], win_w + 1, dev[i], e->S);
     CC_HIP(e->d_haar.ensure(std::max<size_t>(dev.size(), 1)));
     CC_HIP(hipMemcpy(e->d_haar.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice));
   } else {
     lbp_catalog(win_w, win_h, e->lbp);
     e->nfeat = (int)(e->lbp.size() / 4);
     std::vector<LbpFeatDev> dev((size_t)e->nfeat);
-    for (int i = 0; i < e->nfeat; i++) lbp_to_dev(&e->lbp[(size_t)i * 4], win_w + 1, dev[i]);
+    for (int i = 0; i < e->nfeat; i++) lbp_to_dev(&e->lbp[(size_t)i * 4], win_w + 1, dev[i], e->S);
     CC_HIP(e->d_lbp.ensure(std::max<size_t>(dev.size(), 1)));
     CC_HIP(hipMemcpy(e->d_lbp.p, dev.data(), dev.size() * sizeof(LbpFeatDev), hipMemcpyHostToDevice));
   }
@@ -561,7 +574,7 @@ cc_status cc_eval_calc_custom_haar(cc_evaluator* e, const cc_haar_feature* feats
       ok = ok && (f.tilted ? (x - h >= 0 && x + w <= e->W && y + w + h <= e->H) : (x + w <= e->W && y + h <= e->H));
       if (!ok) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc_custom_haar: rect %d of feature %d leaves the window", j, i);
     }
-    haar_to_dev(f, e->W + 1, dev[i]);
+    haar_to_dev(f, e->W + 1, dev[i], e->S);
   }
   std::lock_guard<std::mutex> lk(e->mu);
   const int32_t* d_idx = nullptr;
