@@ -284,32 +284,66 @@ __global__ __launch_bounds__(64) void k_integral_carry(int32_t* __restrict__ hbu
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tilted (45 degree) integral for whole pyramid levels, needed only by cascades with tilted Haar features.
+// With L(y,x) = sum of the pixels on the diagonal going up-left from (y-1, x) and R(y,x) = the same going up-right,
+//   tilted(y, x) = tilted(y-1, x) + p(y-1, x-1) + L(y-1, x-2) + R(y-1, x)
+// (the new bottom pixel of the triangle plus its two new edges), a plain column recurrence; L and R are prefix sums
+// along diagonals: L(y,x) = L(y-1,x-1) + p(y-1,x), R(y,x) = R(y-1,x+1) + p(y-1,x). Pixels outside the image are 0, so
+// every recurrence is border-safe. k_diag_sums: one thread per (anti-)diagonal; k_tilted_cols: one thread per column.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_diag_sums(const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes, int32_t* __restrict__ diag,
+                                                  size_t int_frame_elems, const ScaleDev* __restrict__ sd, int nscales,
+                                                  const int* __restrict__ blk_first) {
+  const int s = find_segment(blk_first, nscales, blockIdx.x);
+  const ScaleDev S = sd[s];
+  const int t = (blockIdx.x - blk_first[s]) * 64 + threadIdx.x;
+  if (t >= S.w + S.h - 1) return;
+  const bool anti = blockIdx.z == 1;  // 0: L (x - y constant), 1: R (x + y constant)
+  const uint8_t* img = pyr + (size_t)blockIdx.y * pyr_frame_bytes + S.img_ofs;
+  int32_t* out = diag + ((size_t)blockIdx.y * 2 + blockIdx.z) * int_frame_elems + S.int_ofs;
+  const int d = anti ? t : t - (S.h - 1);
+  int acc = 0;
+  for (int y = 0; y < S.h; y++) {
+    const int x = anti ? d - y : d + y;
+    if (x >= 0 && x < S.w) {
+      acc += img[(size_t)y * S.pitch8 + x];
+      out[(size_t)(y + 1) * S.pitchI + x] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_tilted_cols(const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+                                                    const int32_t* __restrict__ diag, int32_t* __restrict__ integ,
+                                                    size_t int_frame_elems, int nchan, int tilt_chan,
+                                                    const ScaleDev* __restrict__ sd, int nscales, const int* __restrict__ blk_first) {
+  const int s = find_segment(blk_first, nscales, blockIdx.x);
+  const ScaleDev S = sd[s];
+  const int x = (blockIdx.x - blk_first[s]) * 64 + threadIdx.x;
+  if (x > S.w) return;
+  const uint8_t* img = pyr + (size_t)blockIdx.y * pyr_frame_bytes + S.img_ofs;
+  const int32_t* L = diag + ((size_t)blockIdx.y * 2 + 0) * int_frame_elems + S.int_ofs;
+  const int32_t* R = diag + ((size_t)blockIdx.y * 2 + 1) * int_frame_elems + S.int_ofs;
+  int32_t* T = integ + ((size_t)blockIdx.y * nchan + tilt_chan) * int_frame_elems + S.int_ofs;
+  int acc = 0;
+  T[x] = 0;
+  for (int y = 1; y <= S.h; y++) {
+    int g = x >= 1 ? img[(size_t)(y - 1) * S.pitch8 + (x - 1)] : 0;
+    if (y >= 2) {
+      if (x >= 2) g += L[(size_t)(y - 1) * S.pitchI + (x - 2)];
+      if (x < S.w) g += R[(size_t)(y - 1) * S.pitchI + x];
+    }
+    acc += g;
+    T[(size_t)y * S.pitchI + x] = acc;
+  }
+}
+
 // Calibration stream for the FETCH_SIZE counter: same load shape as stage_tile (dword per lane, coalesced).
 __global__ __launch_bounds__(256) void k_stream_dwords(const uint32_t* __restrict__ p, size_t n_words, uint32_t* __restrict__ out) {
   uint32_t acc = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) acc += p[i];
   if (acc == 0x9e3779b9u) atomicAdd(out, acc);  // keeps the loads alive; practically never taken
   atomicAdd(out + 1 + (threadIdx.x & 15), acc);
-}
-
-// Tilted integral from the finished upright integral (test utility and small images only: O(h) per entry).
-// tilted(Y,X) = sum_{y<Y} rowsum_y[x0..x1], x0 = max(X-1-(Y-y-1),0), x1 = min(X-1+(Y-y-1), w-1);
-// rowsum_y[a..b] = S[y+1][b+1] - S[y][b+1] - S[y+1][a] + S[y][a].
-__global__ void k_tilted_from_sum(const int32_t* __restrict__ sum, int pitchI, int w, int h, int32_t* __restrict__ tilted,
-                                  int tpitch) {
-  const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
-  if (X > w || Y > h) return;
-  int acc = 0;
-  for (int y = 0; y < Y; y++) {
-    const int half = Y - y - 1;
-    const int x0 = max(X - 1 - half, 0), x1 = min(X - 1 + half, w - 1);
-    if (x1 >= x0) {
-      const int32_t* a = sum + (size_t)y * pitchI;
-      const int32_t* b = a + pitchI;
-      acc += b[x1 + 1] - a[x1 + 1] - b[x0] + a[x0];
-    }
-  }
-  tilted[(size_t)Y * tpitch + X] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,9 +381,11 @@ struct TileGeom {
 constexpr int TILE_WINDOWS = TILE_X * TILE_Y;  // 1024
 constexpr int MAX_STAGES = 64;                 // per-stage queue counters live in LDS
 constexpr int PART_DOUBLES = (EVAL_WAVES - 1) * 64;  // partial stage sums of the stump-split phase: (slices-1) x windows
-// LDS bytes per block: integral tile (padded to 8 B) + partial sums + vnf[1024] + 2 queues of u16[1024] + counters
-__host__ __device__ inline size_t eval_lds_bytes(int tile_words) {
-  return (size_t)((tile_words + 1) & ~1) * 4 + PART_DOUBLES * 8 + TILE_WINDOWS * 4 + 2 * TILE_WINDOWS * 2 + MAX_STAGES * 4;
+__host__ __device__ inline int tile_words_padded(int tile_words) { return (tile_words + 3) & ~3; }  // 16-byte multiple
+// LDS bytes per block: integral tile(s) + partial sums + vnf[1024] + 2 queues of u16[1024] + counters
+__host__ __device__ inline size_t eval_lds_bytes(int tile_words, bool tilted) {
+  return (size_t)tile_words_padded(tile_words) * 4 * (tilted ? 2 : 1) + PART_DOUBLES * 8 + TILE_WINDOWS * 4 + 2 * TILE_WINDOWS * 2 +
+         MAX_STAGES * 4;
 }
 
 // Stages the tile of the integral into LDS: one wavefront per tile row, lanes = groups of 4 consecutive entries
@@ -394,6 +430,7 @@ struct EvalArgs {
   const int32_t* integ;
   size_t int_frame_elems;
   int nchan;
+  int tilt_chan;      // channel of the tilted integral, -1 if the cascade has no tilted feature
   const ScaleDev* sd;
   const int4* tiles;  // {scale, tx, ty, 0}
   int W0, H0;
@@ -471,7 +508,7 @@ template <int STEP, bool HAAR>
 __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const int4 T, const ScaleDev& S) {
   using Stump = typename std::conditional<HAAR, HaarStumpDev, LbpStumpDev>::type;
   const TileGeom<STEP> G(A.W0, A.H0);
-  double* s_part = reinterpret_cast<double*>(lds + ((G.words() + 1) & ~1));
+  double* s_part = reinterpret_cast<double*>(lds + tile_words_padded(G.words()) * ((HAAR && A.tilt_chan >= 0) ? 2 : 1));
   float* s_vnf = reinterpret_cast<float*>(s_part + PART_DOUBLES);
   unsigned short* s_q = reinterpret_cast<unsigned short*>(s_vnf + TILE_WINDOWS);  // two buffers of TILE_WINDOWS
   int* s_cnt = reinterpret_cast<int*>(s_q + 2 * TILE_WINDOWS);                   // [stage] = windows that reached it
@@ -503,6 +540,9 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
     }
   }
   stage_tile<STEP>(lds, G, sum, S, gx0 * STEP, gy0 * STEP);
+  if (HAAR && A.tilt_chan >= 0)  // second tile right behind the first: tilted stumps simply carry offsets shifted by it
+    stage_tile<STEP>(lds + tile_words_padded(G.words()), G,
+                     A.integ + ((size_t)frame * A.nchan + A.tilt_chan) * A.int_frame_elems + S.int_ofs, S, gx0 * STEP, gy0 * STEP);
   if (threadIdx.x < MAX_STAGES) s_cnt[threadIdx.x] = 0;
   __syncthreads();
 
@@ -832,11 +872,11 @@ struct Plan {
   std::vector<ScaleDev> sd;
   size_t pyr_frame_bytes = 0, int_frame_elems = 0, mask_frame_words = 0;
   long long windows = 0, integral_elems = 0;
-  int n_resize_blocks = 0, n_bands = 0, n_col_blocks = 0, n_grid_rows = 0;
+  int n_resize_blocks = 0, n_bands = 0, n_col_blocks = 0, n_grid_rows = 0, n_diag_blocks = 0, n_tcol_blocks = 0;
   size_t h_frame_elems = 0;
   int n_tiles = 0;
   DevBuf<ScaleDev> d_sd;
-  DevBuf<int> d_resize_first, d_band_first, d_col_first, d_gridrow_first, d_xofs, d_yofs;
+  DevBuf<int> d_resize_first, d_band_first, d_col_first, d_gridrow_first, d_diag_first, d_tcol_first, d_xofs, d_yofs;
   DevBuf<uint16_t> d_xw1, d_yw1;
   DevBuf<int4> d_tiles;
 };
@@ -867,7 +907,7 @@ struct cc_detector {
   // plans + workspace
   std::vector<std::unique_ptr<Plan>> plans;
   DevBuf<uint8_t> d_frames, d_pyr;
-  DevBuf<int32_t> d_integ, d_hbuf;
+  DevBuf<int32_t> d_integ, d_hbuf, d_diag;
   DevBuf<unsigned long long> d_masks;
   DevBuf<CandRaw> d_cands;
   // Results of a pass are double-buffered so that the host can fetch and group pass i while the device runs pass i+1.
@@ -956,10 +996,18 @@ static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) 
       const bool used = j < 2 || wt != 0.0f;
       if (j == 2 && wt != 0.0f) d.nrect = 3;
       const int x = used ? r[0] : 0, y = used ? r[1] : 0, rw = used ? r[2] : 0, rh = used ? r[3] : 0;
-      d.ofs[j][0] = G.at(y, x);
-      d.ofs[j][1] = G.at(y, x + rw);
-      d.ofs[j][2] = G.at(y + rh, x);
-      d.ofs[j][3] = G.at(y + rh, x + rw);
+      if (!m.haar_tilted[fi]) {
+        d.ofs[j][0] = G.at(y, x);
+        d.ofs[j][1] = G.at(y, x + rw);
+        d.ofs[j][2] = G.at(y + rh, x);
+        d.ofs[j][3] = G.at(y + rh, x + rw);
+      } else {  // corners of the 45-degree rectangle (CV_TILTED_OFFSETS), read from the tilted tile behind the sum tile
+        const int shift = tile_words_padded(G.words());
+        d.ofs[j][0] = shift + G.at(y, x);
+        d.ofs[j][1] = shift + G.at(y + rh, x - rh);
+        d.ofs[j][2] = shift + G.at(y + rw, x + rw);
+        d.ofs[j][3] = shift + G.at(y + rw + rh, x + rw - rh);
+      }
     }
     d.thr = m.stump_threshold[i];
     d.left = m.stump_left[i];
@@ -1000,6 +1048,7 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
   scale_plan(d->m.win_w, d->m.win_h, w, h, p, P->geom);
   const int ns = (int)P->geom.size();
   std::vector<int> resize_first(ns + 1, 0), band_first(ns + 1, 0), col_first(ns + 1, 0), gridrow_first(ns + 1, 0);
+  std::vector<int> diag_first(ns + 1, 0), tcol_first(ns + 1, 0);
   long long h_ofs = 0;
   std::vector<int> xofs, yofs;
   std::vector<uint16_t> xw1, yw1;
@@ -1045,6 +1094,8 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
     band_first[i + 1] = band_first[i] + S.nbands;
     col_first[i + 1] = col_first[i] + (S.pitchI / 4 + 63) / 64;
     gridrow_first[i + 1] = gridrow_first[i] + g.ny;
+    diag_first[i + 1] = diag_first[i] + (g.w + g.h - 1 + 63) / 64;
+    tcol_first[i + 1] = tcol_first[i] + (g.w + 1 + 63) / 64;
     const int ntx = (g.nx + TILE_X - 1) / TILE_X, nty = (g.ny + TILE_Y - 1) / TILE_Y;
     for (int ty_ = 0; ty_ < nty; ty_++)
       for (int tx_ = 0; tx_ < ntx; tx_++) tiles.push_back(make_int4(i, tx_, ty_, 0));
@@ -1058,6 +1109,8 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
   P->h_frame_elems = (size_t)h_ofs;
   P->n_col_blocks = col_first[ns];
   P->n_grid_rows = gridrow_first[ns];
+  P->n_diag_blocks = diag_first[ns];
+  P->n_tcol_blocks = tcol_first[ns];
   // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2): permute the tile list so that the
   // tiles one XCD receives are neighbours in the image and share their halo rows/columns in that XCD's L2.
   // Placement only changes speed, never results.
@@ -1079,6 +1132,8 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
   CC_HIP(P->d_band_first.upload(band_first, st));
   CC_HIP(P->d_col_first.upload(col_first, st));
   CC_HIP(P->d_gridrow_first.upload(gridrow_first, st));
+  CC_HIP(P->d_diag_first.upload(diag_first, st));
+  CC_HIP(P->d_tcol_first.upload(tcol_first, st));
   CC_HIP(P->d_xofs.upload(xofs, st));
   CC_HIP(P->d_yofs.upload(yofs, st));
   CC_HIP(P->d_xw1.upload(xw1, st));
@@ -1131,7 +1186,7 @@ static void collect_events(cc_detector* d) {
 
 // Integral images of every scale of nf frames: band totals, carry down the bands, finished integral.
 static void launch_integral(hipStream_t st, bool sq, const uint8_t* pyr, size_t pyr_frame_bytes, int32_t* integ,
-                            size_t int_frame_elems, int nchan, int32_t* hbuf, size_t h_frame_elems, const ScaleDev* sd, int ns,
+                            size_t int_frame_elems, int nchan /* channel stride of integ / hbuf */, int32_t* hbuf, size_t h_frame_elems, const ScaleDev* sd, int ns,
                             const int* band_first, int n_bands, const int* col_first, int n_col_blocks, int nf) {
   const dim3 grid((n_bands + 3) / 4, nf);
   if (sq)
@@ -1140,7 +1195,7 @@ static void launch_integral(hipStream_t st, bool sq, const uint8_t* pyr, size_t 
   else
     hipLaunchKernelGGL((k_integral_band<false, false>), grid, dim3(256), 0, st, pyr, pyr_frame_bytes, integ, int_frame_elems, nchan,
                        hbuf, h_frame_elems, sd, ns, band_first, n_bands);
-  hipLaunchKernelGGL(k_integral_carry, dim3(n_col_blocks, nf, nchan), dim3(64), 0, st, hbuf, h_frame_elems, nchan, sd, ns, col_first);
+  hipLaunchKernelGGL(k_integral_carry, dim3(n_col_blocks, nf, sq ? 2 : 1), dim3(64), 0, st, hbuf, h_frame_elems, nchan, sd, ns, col_first);
   if (sq)
     hipLaunchKernelGGL((k_integral_band<true, true>), grid, dim3(256), 0, st, pyr, pyr_frame_bytes, integ, int_frame_elems, nchan,
                        hbuf, h_frame_elems, sd, ns, band_first, n_bands);
@@ -1156,13 +1211,15 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   const int ns = (int)P->sd.size();
   hipStream_t st = d->stream;
   const bool haar = d->m.feature_type == CC_FEATURE_HAAR;
-  const int nchan = haar ? 2 : 1;
+  const bool tilt = haar && d->m.has_tilted;
+  const int nchan = haar ? (tilt ? 3 : 2) : 1;  // sum, sqsum, tilted
   CC_HIP(d->d_counts[slot].ensure(2));
   CC_HIP(hipMemsetAsync(d->d_counts[slot].p, 0, 2 * sizeof(int), st));
   if (ns == 0 || nf == 0) return CC_OK;
   CC_HIP(d->d_pyr.ensure(P->pyr_frame_bytes * (size_t)d->max_batch));
   CC_HIP(d->d_integ.ensure(P->int_frame_elems * (size_t)nchan * (size_t)d->max_batch));
   CC_HIP(d->d_hbuf.ensure(std::max<size_t>(P->h_frame_elems * (size_t)nchan * (size_t)d->max_batch, 4)));
+  if (tilt) CC_HIP(d->d_diag.ensure(P->int_frame_elems * 2 * (size_t)d->max_batch));
   CC_HIP(d->d_masks.ensure(std::max<size_t>(P->mask_frame_words * (size_t)d->max_batch, 1)));
   if (d->cand_cap == 0) d->cand_cap = 1 << 18;
   CC_HIP(d->d_cands.ensure((size_t)d->cand_cap));
@@ -1182,6 +1239,12 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     EvScope ev(d, EV_INTEGRAL);
     launch_integral(st, haar, d->d_pyr.p, P->pyr_frame_bytes, d->d_integ.p, P->int_frame_elems, nchan, d->d_hbuf.p,
                     P->h_frame_elems, P->d_sd.p, ns, P->d_band_first.p, P->n_bands, P->d_col_first.p, P->n_col_blocks, nf);
+    if (tilt) {
+      hipLaunchKernelGGL(k_diag_sums, dim3(P->n_diag_blocks, nf, 2), dim3(64), 0, st, d->d_pyr.p, P->pyr_frame_bytes, d->d_diag.p,
+                         P->int_frame_elems, P->d_sd.p, ns, P->d_diag_first.p);
+      hipLaunchKernelGGL(k_tilted_cols, dim3(P->n_tcol_blocks, nf), dim3(64), 0, st, d->d_pyr.p, P->pyr_frame_bytes, d->d_diag.p,
+                         d->d_integ.p, P->int_frame_elems, nchan, 2, P->d_sd.p, ns, P->d_tcol_first.p);
+    }
   }
   {
     EvScope ev(d, EV_EVAL);
@@ -1189,6 +1252,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.integ = d->d_integ.p;
     A.int_frame_elems = P->int_frame_elems;
     A.nchan = nchan;
+    A.tilt_chan = tilt ? 2 : -1;
     A.sd = P->d_sd.p;
     A.W0 = d->m.win_w;
     A.H0 = d->m.win_h;
@@ -1371,8 +1435,7 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   if (max_batch < 1 || max_batch > 4096) return set_error(CC_ERR_INVALID_ARG, "cc_detector_create: max_batch %d out of range", max_batch);
   if (c->m.max_nodes_per_tree != 1)
     return set_error(CC_ERR_UNSUPPORTED, "cc_detector_create: cascades with trees deeper than stumps are not implemented on the device yet");
-  if (c->m.has_tilted)
-    return set_error(CC_ERR_UNSUPPORTED, "cc_detector_create: tilted Haar features are not implemented in the detection kernels yet");
+
   cc_status st = ensure_device(device);
   if (st != CC_OK) return st;
   std::unique_ptr<cc_detector> d(new cc_detector());
@@ -1383,7 +1446,7 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   d->stream = d->own_stream;
   const TileGeom<1> G1(d->m.win_w, d->m.win_h);
   const TileGeom<2> G2(d->m.win_w, d->m.win_h);
-  d->lds = eval_lds_bytes(std::max(G1.words(), G2.words()));
+  d->lds = eval_lds_bytes(std::max(G1.words(), G2.words()), d->m.has_tilted);
   if ((int)d->m.stage_ntrees.size() >= MAX_STAGES)
     return set_error(CC_ERR_UNSUPPORTED, "cc_detector_create: cascades with %zu stages are not supported (limit %d)",
                      d->m.stage_ntrees.size(), MAX_STAGES - 1);
@@ -1670,10 +1733,18 @@ cc_status cc_integral_u8(int device, const uint8_t* img, int width, int height, 
   const size_t opitch = (size_t)(width + 1) * 4;
   if (sum) CC_HIP(hipMemcpy2D(sum, opitch, d_int.p, (size_t)S.pitchI * 4, opitch, height + 1, hipMemcpyDeviceToHost));
   if (sqsum) CC_HIP(hipMemcpy2D(sqsum, opitch, d_int.p + elems, (size_t)S.pitchI * 4, opitch, height + 1, hipMemcpyDeviceToHost));
-  if (tilted) {
+  if (tilted) {  // same kernels as the detection pipeline
+    DevBuf<int32_t> d_diag;
+    std::vector<int> diag_first{0, (width + height - 1 + 63) / 64}, tcol_first{0, (width + 1 + 63) / 64};
+    DevBuf<int> d_diag_first, d_tcol_first;
+    CC_HIP(d_diag_first.upload(diag_first, nullptr));
+    CC_HIP(d_tcol_first.upload(tcol_first, nullptr));
+    CC_HIP(d_diag.ensure(elems * 2));
     CC_HIP(d_tilt.ensure(elems));
-    hipLaunchKernelGGL(k_tilted_from_sum, dim3((width + 1 + 63) / 64, height + 1), dim3(64), 0, nullptr, d_int.p, S.pitchI, width,
-                       height, d_tilt.p, S.pitchI);
+    hipLaunchKernelGGL(k_diag_sums, dim3(diag_first[1], 1, 2), dim3(64), 0, nullptr, d_img.p, (size_t)0, d_diag.p, elems, d_sd.p, 1,
+                       d_diag_first.p);
+    hipLaunchKernelGGL(k_tilted_cols, dim3(tcol_first[1], 1), dim3(64), 0, nullptr, d_img.p, (size_t)0, d_diag.p, d_tilt.p, elems, 1, 0,
+                       d_sd.p, 1, d_tcol_first.p);
     CC_HIP(hipGetLastError());
     CC_HIP(hipMemcpy2D(tilted, opitch, d_tilt.p, (size_t)S.pitchI * 4, opitch, height + 1, hipMemcpyDeviceToHost));
   }

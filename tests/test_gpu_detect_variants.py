@@ -1,0 +1,56 @@
+"""Detection with the less common cascade shapes: tilted (45 degree) Haar features and trees deeper than stumps.
+Same bar as tests/test_gpu_detect.py: per-window result codes, stage sums, visited flags, candidates and grouped
+rectangles identical to the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import cascadeclassifier_amd as cc
+from cascadeclassifier_amd import detector as det
+from oracle import oracle as orc
+from tests import cascade_factory as cf
+from tests.util import frame_natural, frame_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _calib_windows():
+    img = frame_natural(320, 240, 3)
+    return np.stack([img[y:y + 24, x:x + 24] for y in range(0, 200, 9) for x in range(0, 280, 11)])
+
+
+def _check(xml_text, tmp_path, images, sfs=(1.1, 1.3)):
+    path = os.path.join(tmp_path, "cascade.xml")
+    open(path, "w").write(xml_text)
+    o = orc.load_cascade_xml(path)
+    p = cc.CascadeClassifier()
+    assert p.load_from_string(xml_text), getattr(p, "load_error", "")
+    n_cand = 0
+    for img in images:
+        for sf in sfs:
+            ref = orc.detect_raw(o, img, sf, nthreads=8, full=True)
+            codes, sums, vis = p.debug_windows(img, sf)
+            assert (codes == ref.codes).all(), f"{(codes != ref.codes).sum()} window results differ"
+            assert (sums == ref.sums).all()
+            assert (vis == ref.visited).all()
+            raw = p.detect_raw(img, sf)
+            assert raw.shape == ref.candidates.shape and (raw == ref.candidates).all()
+            for mn in (0, 2):
+                a, b = p.detectMultiScale(img, sf, mn), orc.detect_multiscale(o, img, sf, mn, nthreads=8)
+                assert a.shape == b.shape and (a == b).all()
+            n_cand += len(raw)
+    return n_cand
+
+
+@pytest.mark.parametrize("w,h", [(61, 47), (320, 240), (1000, 37)])
+def test_tilted_integral_of_whole_images(w, h):
+    img = frame_uniform(w, h, 9)
+    assert (det.integral(img, tilted=True)["tilted"] == orc.integral(img, tilted=True)["tilted"]).all()
+
+
+def test_tilted_haar_cascade(tmp_path):
+    xml = cf.tilted_stump_cascade(_calib_windows())
+    assert cc.CascadeClassifier().load_from_string(xml)
+    n = _check(xml, str(tmp_path), [frame_natural(200, 150, 5), frame_natural(333, 127, 6), frame_uniform(120, 90, 7)])
+    assert n > 0
