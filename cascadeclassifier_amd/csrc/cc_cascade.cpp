@@ -199,7 +199,8 @@ cc_status cascade_from_xml(const XmlNode& root, Cascade& c) {
       std::vector<std::string> lt;
       split_tokens(lv->text, lt);
       const int nl = (int)lt.size();
-      if (nl < 2) return set_error(CC_ERR_PARSE, "cascade XML: a tree needs at least 2 leaf values");
+      if (nl != nn + 1)  // upstream advances its leaf cursor by nodeCount + 1 per tree
+        return set_error(CC_ERR_PARSE, "cascade XML: a tree with %d nodes must have %d leaf values (found %d)", nn, nn + 1, nl);
       c.tree_first_node.push_back((int32_t)c.node_left.size());
       c.tree_nnodes.push_back(nn);
       c.tree_first_leaf.push_back((int32_t)c.leaves.size());
@@ -209,6 +210,9 @@ cc_status cascade_from_xml(const XmlNode& root, Cascade& c) {
         if (!to_int(t[0], l) || !to_int(t[1], r) || !to_int(t[2], fi)) return set_error(CC_ERR_PARSE, "cascade XML: malformed internalNodes");
         // child > 0: internal node index inside this tree; child <= 0: leaf index -child
         if (l >= nn || r >= nn || -l >= nl || -r >= nl) return set_error(CC_ERR_PARSE, "cascade XML: tree child index out of range");
+        // the writer numbers internal nodes breadth-first, so a child's index exceeds its parent's; insisting on it
+        // guarantees that walking the tree terminates (a cyclic file would otherwise hang a kernel)
+        if ((l > 0 && l <= k) || (r > 0 && r <= k)) return set_error(CC_ERR_PARSE, "cascade XML: tree child index does not increase (cycle)");
         if (fi < 0 || fi >= nfeat) return set_error(CC_ERR_PARSE, "cascade XML: featureIdx %d out of range (features: %d)", fi, nfeat);
         c.node_left.push_back(l);
         c.node_right.push_back(r);

@@ -89,6 +89,23 @@ struct LbpStumpDev {
   int pad[2];
 };
 
+// Internal tree nodes of cascades deeper than stumps (same corner-offset convention as the stump records);
+// child > 0 = node index inside the tree, child <= 0 = leaf index -child.
+struct HaarNodeDev {
+  int ofs[3][4];
+  float w[3];
+  float thr;
+  int left, right;
+  int nrect;
+  int pad;
+};
+struct LbpNodeDev {
+  int ofs[16];
+  int left, right;
+  int subset[8];
+  int pad[2];
+};
+
 struct CandRaw {
   int frame, scale, gx, gy;
 };
@@ -440,6 +457,12 @@ struct EvalArgs {
   const float* stage_thr;
   const void* stumps1;  // stump tables in STEP-1 / STEP-2 tile coordinates
   const void* stumps2;
+  int trees;            // cascade has trees deeper than stumps: node tables below, no stump tables
+  const void* nodes1;
+  const void* nodes2;
+  const int* tree_root;   // first node of each weak classifier
+  const int* tree_leaf0;  // first leaf value of each weak classifier
+  const float* leaves;
   int wave_below;       // switch to one wavefront per window when fewer windows than this are queued (0 = never)
   int split_stumps;     // stage sums are exact (order-independent): wavefronts may split a stage's stumps
   int stop_after;       // timing experiments only: drop every window still alive after this stage (-1 = off)
@@ -481,6 +504,40 @@ __device__ __forceinline__ double stump_vote(const int32_t* b, const LbpStumpDev
   return (double)((word & (1 << (lbp & 31))) ? sp->left : sp->right);
 }
 
+// One weak classifier that is a tree: walk from the root; each lane follows its own path (predictOrdered /
+// predictCategorical). The loader guarantees child indices increase, so the walk ends.
+__device__ __forceinline__ double tree_vote(const int32_t* b, const HaarNodeDev* __restrict__ nodes, int root, int leaf0,
+                                            const float* __restrict__ leaves, float vnf) {
+  int idx = 0;
+  do {
+    const HaarNodeDev* n = nodes + root + idx;
+    const int r0 = b[n->ofs[0][0]] - b[n->ofs[0][1]] - b[n->ofs[0][2]] + b[n->ofs[0][3]];
+    const int r1 = b[n->ofs[1][0]] - b[n->ofs[1][1]] - b[n->ofs[1][2]] + b[n->ofs[1][3]];
+    float v = n->w[0] * (float)r0 + n->w[1] * (float)r1;
+    if (n->nrect == 3) v += n->w[2] * (float)(b[n->ofs[2][0]] - b[n->ofs[2][1]] - b[n->ofs[2][2]] + b[n->ofs[2][3]]);
+    v *= vnf;
+    idx = v < n->thr ? n->left : n->right;
+  } while (idx > 0);
+  return (double)leaves[leaf0 - idx];
+}
+__device__ __forceinline__ double tree_vote(const int32_t* b, const LbpNodeDev* __restrict__ nodes, int root, int leaf0,
+                                            const float* __restrict__ leaves, float) {
+  int idx = 0;
+  do {
+    const LbpNodeDev* n = nodes + root + idx;
+    int p[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) p[j] = b[n->ofs[j]];
+    const int c = p[5] - p[6] - p[9] + p[10];
+    const int lbp = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
+                    (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
+                    (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
+                    (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
+    idx = (n->subset[lbp >> 5] & (1 << (lbp & 31))) ? n->left : n->right;
+  } while (idx > 0);
+  return (double)leaves[leaf0 - idx];
+}
+
 // Sum of `v` over the 64 lanes, returned wave-uniform (in scalar registers). Cross-lane moves are DPP modifiers
 // (quad permutes, row mirrors, row broadcasts), not LDS permutes: ~6 short steps. The order of the additions differs
 // from a sequential sum, so callers use it only where the sum is exact (order-independent).
@@ -504,9 +561,11 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-template <int STEP, bool HAAR>
+template <int STEP, bool HAAR, bool TREES>
 __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const int4 T, const ScaleDev& S) {
   using Stump = typename std::conditional<HAAR, HaarStumpDev, LbpStumpDev>::type;
+  using Node = typename std::conditional<HAAR, HaarNodeDev, LbpNodeDev>::type;
+  const Node* __restrict__ nodes = reinterpret_cast<const Node*>(STEP == 2 ? A.nodes2 : A.nodes1);
   const TileGeom<STEP> G(A.W0, A.H0);
   double* s_part = reinterpret_cast<double*>(lds + tile_words_padded(G.words()) * ((HAAR && A.tilt_chan >= 0) ? 2 : 1));
   float* s_vnf = reinterpret_cast<float*>(s_part + PART_DOUBLES);
@@ -614,7 +673,14 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
     }
     if (__any(any_mine)) {
       const int nt = stage_ntrees[0];
-      if constexpr (HAAR) {
+      if constexpr (TREES) {
+        for (int i = 0; i < nt; i++) {
+          const int root = as_const_table(A.tree_root)[i], leaf0 = as_const_table(A.tree_leaf0)[i];
+#pragma unroll
+          for (int k = 0; k < WIN_PER_THREAD; k++)
+            if (alive[k]) acc[k] += tree_vote(lds + base[k], nodes, root, leaf0, A.leaves, vnf[k]);
+        }
+      } else if constexpr (HAAR) {
         // software pipeline: the next stump record is fetched (scalar loads) while this one is evaluated
         Stump cur = load_record(stumps);
         for (int i = 0; i < nt; i++) {
@@ -691,7 +757,12 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
         const int32_t* b = lds + window_base(id);
         const float vnf = HAAR ? s_vnf[id] : 1.f;
         double acc = 0.;
-        if constexpr (HAAR) {
+        if constexpr (TREES) {
+          for (int j = 0; j < nt; j++) {
+            const int root = as_const_table(A.tree_root)[first + j], leaf0 = as_const_table(A.tree_leaf0)[first + j];
+            if (valid) acc += tree_vote(b, nodes, root, leaf0, A.leaves, vnf);
+          }
+        } else if constexpr (HAAR) {
           Stump cur = load_record(stumps + first);
           for (int j = 0; j < nt; j++) {
             const Stump nxt = load_record(stumps + first + min(j + 1, nt - 1));
@@ -765,20 +836,30 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval_haar(EvalArgs A) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const int4 T = load_record(as_const_table(A.tiles) + blockIdx.x);
   const ScaleDev S = load_record(as_const_table(A.sd) + T.x);
-  if (S.ystep == 2)
-    eval_tile<2, true>(A, lds, T, S);
+  if (A.trees) {  // rare: cascades with trees deeper than stumps (thread-per-window phases only)
+    if (S.ystep == 2)
+      eval_tile<2, true, true>(A, lds, T, S);
+    else
+      eval_tile<1, true, true>(A, lds, T, S);
+  } else if (S.ystep == 2)
+    eval_tile<2, true, false>(A, lds, T, S);
   else
-    eval_tile<1, true>(A, lds, T, S);
+    eval_tile<1, true, false>(A, lds, T, S);
 }
 
 __global__ __launch_bounds__(EVAL_THREADS) void k_eval_lbp(EvalArgs A) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const int4 T = load_record(as_const_table(A.tiles) + blockIdx.x);
   const ScaleDev S = load_record(as_const_table(A.sd) + T.x);
-  if (S.ystep == 2)
-    eval_tile<2, false>(A, lds, T, S);
+  if (A.trees) {
+    if (S.ystep == 2)
+      eval_tile<2, false, true>(A, lds, T, S);
+    else
+      eval_tile<1, false, true>(A, lds, T, S);
+  } else if (S.ystep == 2)
+    eval_tile<2, false, false>(A, lds, T, S);
   else
-    eval_tile<1, false>(A, lds, T, S);
+    eval_tile<1, false, false>(A, lds, T, S);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -903,6 +984,10 @@ struct cc_detector {
   int split_stumps = 0;
   DevBuf<HaarStumpDev> d_haar1, d_haar2;
   DevBuf<LbpStumpDev> d_lbp1, d_lbp2;
+  DevBuf<HaarNodeDev> d_hnode1, d_hnode2;  // cascades with trees deeper than stumps
+  DevBuf<LbpNodeDev> d_lnode1, d_lnode2;
+  DevBuf<int> d_tree_root, d_tree_leaf0;
+  DevBuf<float> d_leaves;
   size_t lds = 0;  // dynamic LDS bytes per tile (larger of the two layouts)
   // plans + workspace
   std::vector<std::unique_ptr<Plan>> plans;
@@ -1012,6 +1097,57 @@ static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) 
     d.thr = m.stump_threshold[i];
     d.left = m.stump_left[i];
     d.right = m.stump_right[i];
+  }
+}
+
+template <int STEP>
+static void build_haar_nodes(const Cascade& m, std::vector<HaarNodeDev>& out) {
+  const TileGeom<STEP> G(m.win_w, m.win_h);
+  out.resize(m.node_feature.size());
+  for (size_t i = 0; i < out.size(); i++) {
+    HaarNodeDev& d = out[i];
+    std::memset(&d, 0, sizeof(d));
+    const int fi = m.node_feature[i];
+    d.nrect = 2;
+    for (int j = 0; j < 3; j++) {
+      const int32_t* r = &m.haar_rects[(size_t)fi * 12 + j * 4];
+      const float wt = m.haar_weights[(size_t)fi * 3 + j];
+      d.w[j] = wt;
+      const bool used = j < 2 || wt != 0.0f;
+      if (j == 2 && wt != 0.0f) d.nrect = 3;
+      const int x = used ? r[0] : 0, y = used ? r[1] : 0, rw = used ? r[2] : 0, rh = used ? r[3] : 0;
+      if (!m.haar_tilted[fi]) {
+        d.ofs[j][0] = G.at(y, x);
+        d.ofs[j][1] = G.at(y, x + rw);
+        d.ofs[j][2] = G.at(y + rh, x);
+        d.ofs[j][3] = G.at(y + rh, x + rw);
+      } else {
+        const int shift = tile_words_padded(G.words());
+        d.ofs[j][0] = shift + G.at(y, x);
+        d.ofs[j][1] = shift + G.at(y + rh, x - rh);
+        d.ofs[j][2] = shift + G.at(y + rw, x + rw);
+        d.ofs[j][3] = shift + G.at(y + rw + rh, x + rw - rh);
+      }
+    }
+    d.thr = m.node_threshold[i];
+    d.left = m.node_left[i];
+    d.right = m.node_right[i];
+  }
+}
+
+template <int STEP>
+static void build_lbp_nodes(const Cascade& m, std::vector<LbpNodeDev>& out) {
+  const TileGeom<STEP> G(m.win_w, m.win_h);
+  out.resize(m.node_feature.size());
+  for (size_t i = 0; i < out.size(); i++) {
+    LbpNodeDev& d = out[i];
+    std::memset(&d, 0, sizeof(d));
+    const int32_t* r = &m.lbp_rects[(size_t)m.node_feature[i] * 4];
+    for (int rr = 0; rr < 4; rr++)
+      for (int cc = 0; cc < 4; cc++) d.ofs[4 * rr + cc] = G.at(r[1] + rr * r[3], r[0] + cc * r[2]);
+    d.left = m.node_left[i];
+    d.right = m.node_right[i];
+    for (int j = 0; j < 8; j++) d.subset[j] = m.node_subset[i * 8 + j];
   }
 }
 
@@ -1273,6 +1409,12 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.tiles = P->d_tiles.p;
     A.stumps1 = haar ? (const void*)d->d_haar1.p : (const void*)d->d_lbp1.p;
     A.stumps2 = haar ? (const void*)d->d_haar2.p : (const void*)d->d_lbp2.p;
+    A.trees = d->m.max_nodes_per_tree > 1 ? 1 : 0;
+    A.nodes1 = haar ? (const void*)d->d_hnode1.p : (const void*)d->d_lnode1.p;
+    A.nodes2 = haar ? (const void*)d->d_hnode2.p : (const void*)d->d_lnode2.p;
+    A.tree_root = d->d_tree_root.p;
+    A.tree_leaf0 = d->d_tree_leaf0.p;
+    A.leaves = d->d_leaves.p;
     if (P->n_tiles) {
       if (haar)
         hipLaunchKernelGGL(k_eval_haar, dim3(P->n_tiles, nf), dim3(EVAL_THREADS), d->lds, st, A);
@@ -1433,8 +1575,6 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   if (!c || !out) return set_error(CC_ERR_INVALID_ARG, "cc_detector_create: null argument");
   *out = nullptr;
   if (max_batch < 1 || max_batch > 4096) return set_error(CC_ERR_INVALID_ARG, "cc_detector_create: max_batch %d out of range", max_batch);
-  if (c->m.max_nodes_per_tree != 1)
-    return set_error(CC_ERR_UNSUPPORTED, "cc_detector_create: cascades with trees deeper than stumps are not implemented on the device yet");
 
   cc_status st = ensure_device(device);
   if (st != CC_OK) return st;
@@ -1466,7 +1606,8 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   CC_HIP(d->d_stage_first.upload(sfirst, d->stream));
   // One wavefront per window (parallel reduction of a stage's votes) is only bit-identical to the sequential CPU sum
   // when every partial sum is exact in double; LBP stages are too short for it to pay.
-  const bool exact = stage_sums_order_independent(d->m);
+  const bool trees = d->m.max_nodes_per_tree > 1;  // general trees: thread-per-window phases only, sequential sums
+  const bool exact = !trees && stage_sums_order_independent(d->m);
   d->wave_below = (haar && exact) ? 24 : 0;
   d->split_stumps = exact ? 1 : 0;
   if (const char* e = std::getenv("CCAMD_SPLIT_STUMPS")) d->split_stumps = d->split_stumps && std::atoi(e) != 0;
@@ -1479,7 +1620,27 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   if (const char* e = std::getenv("CCAMD_WAVE_BELOW"))  // tuning knob; only honoured when the reduction is exact
     if (d->wave_below) d->wave_below = std::max(0, std::atoi(e));
   CC_HIP(d->d_stage_thr.upload(d->m.stage_threshold, d->stream));
-  if (haar) {
+  if (trees) {
+    std::vector<int> root(d->m.tree_first_node.begin(), d->m.tree_first_node.end()), leaf0(d->m.tree_first_leaf.begin(), d->m.tree_first_leaf.end());
+    CC_HIP(d->d_tree_root.upload(root, d->stream));
+    CC_HIP(d->d_tree_leaf0.upload(leaf0, d->stream));
+    CC_HIP(d->d_leaves.upload(d->m.leaves, d->stream));
+    if (haar) {
+      std::vector<HaarNodeDev> n1, n2;
+      build_haar_nodes<1>(d->m, n1);
+      build_haar_nodes<2>(d->m, n2);
+      CC_HIP(d->d_hnode1.upload(n1, d->stream));
+      CC_HIP(d->d_hnode2.upload(n2, d->stream));
+      CC_HIP(hipStreamSynchronize(d->stream));
+    } else {
+      std::vector<LbpNodeDev> n1, n2;
+      build_lbp_nodes<1>(d->m, n1);
+      build_lbp_nodes<2>(d->m, n2);
+      CC_HIP(d->d_lnode1.upload(n1, d->stream));
+      CC_HIP(d->d_lnode2.upload(n2, d->stream));
+      CC_HIP(hipStreamSynchronize(d->stream));
+    }
+  } else if (haar) {
     std::vector<HaarStumpDev> s1, s2;
     build_haar_stumps<1>(d->m, s1);
     build_haar_stumps<2>(d->m, s2);

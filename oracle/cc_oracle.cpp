@@ -387,6 +387,17 @@ struct OrcCascade {
   int32_t nfeatures;
   const OrcHaarFeature* haar;      // [nfeatures] (Haar)
   const int32_t* lbp_rect;         // [nfeatures*4] (LBP)
+  // General trees (used when max_nodes_per_tree > 1). Weak classifier t has tree_nnodes[t] nodes,
+  // stored consecutively; child > 0 = node index inside the tree, child <= 0 = leaf index -child; upstream advances its
+  // leaf cursor by nodeCount + 1 per tree.
+  int32_t max_nodes_per_tree;
+  const int32_t* tree_nnodes;      // [nstumps] (= number of weak classifiers)
+  const int32_t* node_left;
+  const int32_t* node_right;
+  const int32_t* node_feature;
+  const float* node_threshold;
+  const int32_t* node_subset;      // [nnodes*subset_size]
+  const float* leaves;
 };
 
 struct OrcScale {
@@ -494,6 +505,37 @@ inline int run_at(const OrcCascade& c, const std::vector<float>& stage_thr, cons
   }
   int si = 0;
   double tmp = 0;
+  if (c.max_nodes_per_tree > 1) {  // predictOrdered / predictCategorical: walk each tree from its root
+    int nodeOfs = 0, leafOfs = 0;
+    for (int st = 0; st < c.nstages; st++) {
+      tmp = 0;
+      for (int i = 0; i < c.stage_ntrees[st]; i++, si++) {
+        int idx = 0;
+        const int root = nodeOfs;
+        do {
+          const int n = root + idx;
+          if (c.feature_type == 0) {
+            const OrcHaarFeature& f = c.haar[c.node_feature[n]];
+            const double val = haar_calc(f, f.tilted ? ptilt : pwin, step) * vnf;
+            idx = val < c.node_threshold[n] ? c.node_left[n] : c.node_right[n];
+          } else {
+            const int code = lbp_calc(c.lbp_rect + 4 * c.node_feature[n], pwin, step);
+            const int32_t* subset = c.node_subset + (size_t)n * c.subset_size;
+            idx = (subset[code >> 5] & (1 << (code & 31))) ? c.node_left[n] : c.node_right[n];
+          }
+        } while (idx > 0);
+        tmp += c.leaves[leafOfs - idx];
+        nodeOfs += c.tree_nnodes[si];
+        leafOfs += c.tree_nnodes[si] + 1;
+      }
+      if (tmp < stage_thr[st]) {
+        *last_sum = tmp;
+        return -st;
+      }
+    }
+    *last_sum = tmp;
+    return 1;
+  }
   for (int st = 0; st < c.nstages; st++) {
     tmp = 0;
     int nt = c.stage_ntrees[st];

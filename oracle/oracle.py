@@ -39,6 +39,8 @@ class _Cascade(C.Structure):
         ("stump_feature", C.c_void_p), ("stump_threshold", C.c_void_p), ("stump_left", C.c_void_p),
         ("stump_right", C.c_void_p), ("subset_size", C.c_int32), ("stump_subset", C.c_void_p),
         ("nfeatures", C.c_int32), ("haar", C.c_void_p), ("lbp_rect", C.c_void_p),
+        ("max_nodes_per_tree", C.c_int32), ("tree_nnodes", C.c_void_p), ("node_left", C.c_void_p), ("node_right", C.c_void_p),
+        ("node_feature", C.c_void_p), ("node_threshold", C.c_void_p), ("node_subset", C.c_void_p), ("leaves", C.c_void_p),
     ]
 
 
@@ -169,6 +171,13 @@ class Cascade:
     haar: np.ndarray
     lbp_rect: np.ndarray
     max_nodes_per_tree: int = 1
+    tree_nnodes: np.ndarray = None
+    node_left: np.ndarray = None
+    node_right: np.ndarray = None
+    node_feature: np.ndarray = None
+    node_threshold: np.ndarray = None
+    node_subset: np.ndarray = None
+    leaves: np.ndarray = None
     _keep: list = field(default_factory=list)
 
     @property
@@ -188,12 +197,14 @@ class Cascade:
                      _p(self.stage_threshold).value, self.nstumps, _p(self.stump_feature).value,
                      _p(self.stump_threshold).value, _p(self.stump_left).value, _p(self.stump_right).value,
                      self.subset_size, _p(self.stump_subset).value, self.nfeatures, _p(self.haar).value,
-                     _p(self.lbp_rect).value)
+                     _p(self.lbp_rect).value, self.max_nodes_per_tree, _p(self.tree_nnodes).value, _p(self.node_left).value,
+                     _p(self.node_right).value, _p(self.node_feature).value, _p(self.node_threshold).value,
+                     _p(self.node_subset).value, _p(self.leaves).value)
         return c
 
 
 def load_cascade_xml(path: str) -> Cascade:
-    """Independent (ElementTree) reader of the new-format cascade XML. Stumps only."""
+    """Independent (ElementTree) reader of the new-format cascade XML."""
     root = ET.parse(path).getroot()
     casc = root.find("cascade")
     if casc is None:  # first child of <opencv_storage>
@@ -208,6 +219,7 @@ def load_cascade_xml(path: str) -> Cascade:
     subset = (max_cat + 31) // 32 if max_cat > 0 else 0
     node_step = 3 + (subset if max_cat > 0 else 1)
     ntrees, sthr, sf, st, sl, sr, ss = [], [], [], [], [], [], []
+    t_nn, n_l, n_r, n_f, n_t, n_s, lv = [], [], [], [], [], [], []
     max_nodes = 0
     for stage in casc.find("stages"):
         if stage.tag != "_":
@@ -220,10 +232,21 @@ def load_cascade_xml(path: str) -> Cascade:
             leaves = [np.float32(float(v)) for v in w.findtext("leafValues").split()]
             nn = len(toks) // node_step
             max_nodes = max(max_nodes, nn)
-            assert nn == 1, "oracle.load_cascade_xml: stumps only"
-            left, right, fidx = int(toks[0]), int(toks[1]), int(toks[2])
-            assert left == 0 and right == -1
-            sf.append(fidx)
+            assert len(leaves) == nn + 1, "a tree with n nodes has n + 1 leaves"
+            t_nn.append(nn)
+            lv.extend(leaves)
+            for k in range(nn):
+                t = toks[k * node_step:(k + 1) * node_step]
+                n_l.append(int(t[0]))
+                n_r.append(int(t[1]))
+                n_f.append(int(t[2]))
+                if subset:
+                    n_s.extend(int(v) for v in t[3:3 + subset])
+                    n_t.append(np.float32(0))
+                else:
+                    n_t.append(np.float32(float(t[3])))
+            # stump view (first node; meaningful when every tree is a stump)
+            sf.append(int(toks[2]))
             if subset:
                 ss.extend(int(v) for v in toks[3:3 + subset])
                 st.append(np.float32(0))
@@ -246,7 +269,9 @@ def load_cascade_xml(path: str) -> Cascade:
             lbp[i] = [int(v) for v in f.findtext("rect").split()]
     return Cascade(0 if ftype == "HAAR" else 1, W, H, np.array(ntrees, np.int32), np.array(sthr, np.float32),
                    np.array(sf, np.int32), np.array(st, np.float32), np.array(sl, np.float32), np.array(sr, np.float32),
-                   subset, np.array(ss, np.int32), haar, lbp, max_nodes)
+                   subset, np.array(ss, np.int32), haar, lbp, max_nodes, np.array(t_nn, np.int32), np.array(n_l, np.int32),
+                   np.array(n_r, np.int32), np.array(n_f, np.int32), np.array(n_t, np.float32), np.array(n_s, np.int32),
+                   np.array(lv, np.float32))
 
 
 # ------------------------------------------------------------------ detection

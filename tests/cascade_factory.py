@@ -64,3 +64,76 @@ def tilted_stump_cascade(windows, seed=11, stage_sizes=(6, 10, 14, 20)):
         stages.append((st, weaks))
         k += nw
     return haar_xml(feats, stages)
+
+
+def lbp_xml(rects, stages, W=24, H=24):
+    """rects: (n,4) cell rects; stages: list of (threshold, [weak]) with weak = (nodes, leaves),
+    nodes = list of (left, right, feature_idx, [8 subset words])."""
+    L = ['<?xml version="1.0"?>', "<opencv_storage>", '<cascade type_id="opencv-cascade-classifier">', "  <stageType>BOOST</stageType>",
+         "  <featureType>LBP</featureType>", f"  <height>{H}</height>", f"  <width>{W}</width>",
+         "  <featureParams><maxCatCount>256</maxCatCount><featSize>1</featSize></featureParams>", f"  <stageNum>{len(stages)}</stageNum>",
+         "  <stages>"]
+    for thr, weaks in stages:
+        L.append("    <_><maxWeakCount>%d</maxWeakCount><stageThreshold>%.8e</stageThreshold><weakClassifiers>" % (len(weaks), thr))
+        for nodes, leaves in weaks:
+            flat = " ".join("%d %d %d %s" % (l, r, f, " ".join(str(int(w)) for w in sub)) for (l, r, f, sub) in nodes)
+            L.append("      <_><internalNodes>%s</internalNodes><leafValues>%s</leafValues></_>" % (flat, " ".join("%.8e" % v for v in leaves)))
+        L.append("    </weakClassifiers></_>")
+    L.append("  </stages>")
+    L.append("  <features>")
+    for r in rects:
+        L.append("    <_><rect>%d %d %d %d</rect></_>" % tuple(int(v) for v in r))
+    L += ["  </features>", "</cascade>", "</opencv_storage>"]
+    return "\n".join(L) + "\n"
+
+
+# tree shapes in the writer's convention (internal children: positive BFS index; leaves: 0, -1, -2, ... in emission order)
+_SHAPES = [
+    [(0, -1)],                       # stump
+    [(1, 2), (0, -1), (-2, -3)],     # full depth 2
+    [(0, 1), (-1, -2)],              # left leaf, right subtree
+    [(1, -2), (0, -1)],              # left subtree, right leaf
+    [(1, 2), (3, 0), (-1, -2), (-3, -4)],  # depth 3, unbalanced
+]
+
+
+def haar_tree_cascade(windows, seed=21, stage_sizes=(4, 6, 8), with_tilted=False):
+    rng = np.random.default_rng(seed)
+    cat = orc.haar_catalog(24, 24, 2 if with_tilted else 0)
+    pool = np.nonzero(cat["r"][:, 0, 2] * cat["r"][:, 0, 3] >= 16)[0]
+    shapes = [_SHAPES[int(rng.integers(0, len(_SHAPES)))] for _ in range(sum(stage_sizes))]
+    n_nodes = sum(len(sh) for sh in shapes)
+    feats = cat[rng.choice(pool, n_nodes, replace=False)].copy()
+    med = np.median(calibration_values(feats, windows), axis=1).astype(np.float32)
+    stages, t, fi = [], 0, 0
+    for nw in stage_sizes:
+        weaks = []
+        for _ in range(nw):
+            sh = shapes[t]
+            nodes = [(l, r, fi + k, med[fi + k]) for k, (l, r) in enumerate(sh)]
+            leaves = rng.uniform(-1, 1, len(sh) + 1).astype(np.float32)
+            weaks.append((nodes, leaves))
+            fi += len(sh)
+            t += 1
+        stages.append((np.float32(-0.15 * nw), weaks))
+    return haar_xml(feats, stages, mode="ALL" if with_tilted else "BASIC")
+
+
+def lbp_tree_cascade(seed=31, stage_sizes=(3, 4, 5, 6)):
+    rng = np.random.default_rng(seed)
+    cat = orc.lbp_catalog(24, 24)
+    shapes = [_SHAPES[int(rng.integers(0, len(_SHAPES)))] for _ in range(sum(stage_sizes))]
+    n_nodes = sum(len(sh) for sh in shapes)
+    rects = cat[rng.choice(len(cat), n_nodes, replace=False)]
+    stages, t, fi = [], 0, 0
+    for nw in stage_sizes:
+        weaks = []
+        for _ in range(nw):
+            sh = shapes[t]
+            nodes = [(l, r, fi + k, rng.integers(-2**31, 2**31, 8)) for k, (l, r) in enumerate(sh)]
+            leaves = rng.uniform(-1, 1, len(sh) + 1).astype(np.float32)
+            weaks.append((nodes, leaves))
+            fi += len(sh)
+            t += 1
+        stages.append((np.float32(-0.1 * nw), weaks))
+    return lbp_xml(rects, stages)

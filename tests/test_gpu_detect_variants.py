@@ -54,3 +54,25 @@ def test_tilted_haar_cascade(tmp_path):
     assert cc.CascadeClassifier().load_from_string(xml)
     n = _check(xml, str(tmp_path), [frame_natural(200, 150, 5), frame_natural(333, 127, 6), frame_uniform(120, 90, 7)])
     assert n > 0
+
+
+@pytest.mark.parametrize("with_tilted", [False, True])
+def test_haar_trees_deeper_than_stumps(tmp_path, with_tilted):
+    xml = cf.haar_tree_cascade(_calib_windows(), with_tilted=with_tilted)
+    p = cc.CascadeClassifier()
+    assert p.load_from_string(xml) and p.info()["max_nodes_per_tree"] == 4
+    n = _check(xml, str(tmp_path), [frame_natural(200, 150, 15), frame_natural(97, 211, 16)])
+    assert n > 0
+
+
+def test_lbp_trees_deeper_than_stumps(tmp_path):
+    xml = cf.lbp_tree_cascade()
+    n = _check(xml, str(tmp_path), [frame_natural(200, 150, 25), frame_uniform(150, 100, 26)])
+    assert n > 0
+
+
+def test_cyclic_tree_is_refused():
+    xml = cf.lbp_tree_cascade().replace("<internalNodes>1 2 ", "<internalNodes>0 2 ", 1) if False else None
+    bad = cf.haar_xml(orc.haar_catalog(24, 24, 0)[:2], [(np.float32(0), [([(1, -1, 0, np.float32(0)), (1, -2, 1, np.float32(0))], [0.1, 0.2, 0.3])])])
+    p = cc.CascadeClassifier()
+    assert not p.load_from_string(bad) and "cycle" in p.load_error
