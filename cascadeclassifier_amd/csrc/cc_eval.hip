@@ -192,7 +192,14 @@ struct PredictArgs {
   const float* stump_thr;
   const float* stump_left;
   const float* stump_right;
-  const int* subsets;      // 8 words per stump (LBP)
+  const int* subsets;      // 8 words per stump / node (LBP)
+  // general trees (max_nodes_per_tree > 1): feats / stump_thr / subsets are then indexed by NODE
+  int trees;
+  const int* tree_root;
+  const int* tree_leaf0;
+  const int* node_left;
+  const int* node_right;
+  const float* leaves;
   uint8_t* out;
 };
 
@@ -210,6 +217,37 @@ __global__ __launch_bounds__(64) void k_predict(PredictArgs A) {
     double acc = 0;
     const int nt = A.stage_ntrees[st];
     for (int i = 0; i < nt; i++, k++) {
+      if (A.trees) {  // CvCascadeBoostTree::predict on a general tree: ordered "<= goes left", categorical "bit set goes left"
+        int idx = 0;
+        const int root = A.tree_root[k];
+        do {
+          const int n = root + idx;
+          bool go_left;
+          if (HAAR) {
+            const HaarFeatDev F = reinterpret_cast<const HaarFeatDev*>(A.feats)[n];
+            const int32_t* b = F.tilted ? timg : img;
+            float ret = F.w[0] * (float)(b[F.p[0][0]] - b[F.p[0][1]] - b[F.p[0][2]] + b[F.p[0][3]]) +
+                        F.w[1] * (float)(b[F.p[1][0]] - b[F.p[1][1]] - b[F.p[1][2]] + b[F.p[1][3]]);
+            if (F.w[2] != 0.0f) ret += F.w[2] * (float)(b[F.p[2][0]] - b[F.p[2][1]] - b[F.p[2][2]] + b[F.p[2][3]]);
+            const float val = nf == 0.0f ? 0.0f : ret / nf;
+            go_left = val <= A.stump_thr[n];
+          } else {
+            const LbpFeatDev F = reinterpret_cast<const LbpFeatDev*>(A.feats)[n];
+            int p[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) p[j] = img[F.p[j]];
+            const int c = p[5] - p[6] - p[9] + p[10];
+            const int code = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
+                             (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
+                             (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
+                             (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
+            go_left = (A.subsets[(size_t)n * 8 + (code >> 5)] & (1 << (code & 31))) != 0;
+          }
+          idx = go_left ? A.node_left[n] : A.node_right[n];
+        } while (idx > 0);
+        acc += (double)A.leaves[A.tree_leaf0[k] - idx];
+        continue;
+      }
       if (HAAR) {
         const HaarFeatDev F = reinterpret_cast<const HaarFeatDev*>(A.feats)[k];
         const int32_t* b = F.tilted ? timg : img;
@@ -662,7 +700,6 @@ cc_status cc_eval_predict_cascade(cc_evaluator* e, const cc_cascade* c, const in
   if (m.feature_type != e->type || m.win_w != e->W || m.win_h != e->H)
     return set_error(CC_ERR_INVALID_ARG, "cc_eval_predict_cascade: cascade (%s %dx%d) does not match the evaluator (%dx%d)",
                      m.feature_type == CC_FEATURE_HAAR ? "HAAR" : "LBP", m.win_w, m.win_h, e->W, e->H);
-  if (m.max_nodes_per_tree != 1) return set_error(CC_ERR_UNSUPPORTED, "cc_eval_predict_cascade: trees deeper than stumps are not implemented on the device yet");
   if (m.has_tilted && !e->use_tilted) return set_error(CC_ERR_INVALID_ARG, "cc_eval_predict_cascade: cascade has tilted features but the evaluator keeps no tilted integrals");
   if (n_samples < 0) return set_error(CC_ERR_INVALID_ARG, "cc_eval_predict_cascade: negative sample count");
   cc_status st = eval_device(e);
@@ -673,7 +710,11 @@ cc_status cc_eval_predict_cascade(cc_evaluator* e, const cc_cascade* c, const in
   st = upload_indices(e, sample_idx, n_samples, &d_idx);
   if (st != CC_OK) return st;
   const bool haar = e->type == CC_FEATURE_HAAR;
-  const size_t ns = m.stump_feature.size();
+  const bool trees = m.max_nodes_per_tree > 1;
+  // per-record tables are indexed by stump for stump cascades and by node for general trees
+  const std::vector<int32_t>& rec_feature = trees ? m.node_feature : m.stump_feature;
+  const std::vector<float>& rec_thr = trees ? m.node_threshold : m.stump_threshold;
+  const size_t ns = rec_feature.size();
   EBuf<HaarFeatDev> dh;
   EBuf<LbpFeatDev> dl;
   EBuf<int> d_ntrees, d_sub;
@@ -683,7 +724,7 @@ cc_status cc_eval_predict_cascade(cc_evaluator* e, const cc_cascade* c, const in
     std::vector<HaarFeatDev> dev(ns);
     for (size_t i = 0; i < ns; i++) {
       HaarFeature f;
-      const int fi = m.stump_feature[i];
+      const int fi = rec_feature[i];
       std::memcpy(f.r, &m.haar_rects[(size_t)fi * 12], sizeof(f.r));
       std::memcpy(f.w, &m.haar_weights[(size_t)fi * 3], sizeof(f.w));
       f.tilted = m.haar_tilted[fi];
@@ -693,7 +734,7 @@ cc_status cc_eval_predict_cascade(cc_evaluator* e, const cc_cascade* c, const in
     CC_HIP(hipMemcpy(dh.p, dev.data(), ns * sizeof(HaarFeatDev), hipMemcpyHostToDevice));
   } else {
     std::vector<LbpFeatDev> dev(ns);
-    for (size_t i = 0; i < ns; i++) lbp_to_dev(&m.lbp_rects[(size_t)m.stump_feature[i] * 4], e->W + 1, dev[i]);
+    for (size_t i = 0; i < ns; i++) lbp_to_dev(&m.lbp_rects[(size_t)rec_feature[i] * 4], e->W + 1, dev[i]);
     CC_HIP(dl.ensure(ns));
     CC_HIP(hipMemcpy(dl.p, dev.data(), ns * sizeof(LbpFeatDev), hipMemcpyHostToDevice));
     CC_HIP(d_sub.ensure(ns * 8));
@@ -704,11 +745,27 @@ cc_status cc_eval_predict_cascade(cc_evaluator* e, const cc_cascade* c, const in
   CC_HIP(d_sthr.ensure(ntrees.size()));
   CC_HIP(hipMemcpy(d_sthr.p, m.stage_threshold.data(), ntrees.size() * 4, hipMemcpyHostToDevice));
   CC_HIP(d_thr.ensure(ns));
-  CC_HIP(hipMemcpy(d_thr.p, m.stump_threshold.data(), ns * 4, hipMemcpyHostToDevice));
-  CC_HIP(d_left.ensure(ns));
-  CC_HIP(hipMemcpy(d_left.p, m.stump_left.data(), ns * 4, hipMemcpyHostToDevice));
-  CC_HIP(d_right.ensure(ns));
-  CC_HIP(hipMemcpy(d_right.p, m.stump_right.data(), ns * 4, hipMemcpyHostToDevice));
+  CC_HIP(hipMemcpy(d_thr.p, rec_thr.data(), ns * 4, hipMemcpyHostToDevice));
+  EBuf<int> d_root, d_leaf0, d_nl, d_nr;
+  EBuf<float> d_leaves;
+  if (!trees) {
+    CC_HIP(d_left.ensure(ns));
+    CC_HIP(hipMemcpy(d_left.p, m.stump_left.data(), ns * 4, hipMemcpyHostToDevice));
+    CC_HIP(d_right.ensure(ns));
+    CC_HIP(hipMemcpy(d_right.p, m.stump_right.data(), ns * 4, hipMemcpyHostToDevice));
+  } else {
+    const size_t nt = m.tree_first_node.size();
+    CC_HIP(d_root.ensure(nt));
+    CC_HIP(hipMemcpy(d_root.p, m.tree_first_node.data(), nt * 4, hipMemcpyHostToDevice));
+    CC_HIP(d_leaf0.ensure(nt));
+    CC_HIP(hipMemcpy(d_leaf0.p, m.tree_first_leaf.data(), nt * 4, hipMemcpyHostToDevice));
+    CC_HIP(d_nl.ensure(ns));
+    CC_HIP(hipMemcpy(d_nl.p, m.node_left.data(), ns * 4, hipMemcpyHostToDevice));
+    CC_HIP(d_nr.ensure(ns));
+    CC_HIP(hipMemcpy(d_nr.p, m.node_right.data(), ns * 4, hipMemcpyHostToDevice));
+    CC_HIP(d_leaves.ensure(m.leaves.size()));
+    CC_HIP(hipMemcpy(d_leaves.p, m.leaves.data(), m.leaves.size() * 4, hipMemcpyHostToDevice));
+  }
   CC_HIP(e->d_pred.ensure((size_t)n_samples));
   PredictArgs A;
   A.sum = e->d_sum.p;
@@ -725,6 +782,12 @@ cc_status cc_eval_predict_cascade(cc_evaluator* e, const cc_cascade* c, const in
   A.stump_left = d_left.p;
   A.stump_right = d_right.p;
   A.subsets = d_sub.p;
+  A.trees = trees ? 1 : 0;
+  A.tree_root = d_root.p;
+  A.tree_leaf0 = d_leaf0.p;
+  A.node_left = d_nl.p;
+  A.node_right = d_nr.p;
+  A.leaves = d_leaves.p;
   A.out = e->d_pred.p;
   if (haar)
     hipLaunchKernelGGL(k_predict<true>, dim3((n_samples + 63) / 64), dim3(64), 0, e->stream, A);

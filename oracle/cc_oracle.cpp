@@ -779,6 +779,33 @@ ORC_API int orc_train_predict(const OrcCascade* c, const int32_t* sum, const int
   const int32_t* img = sum + (size_t)si * cols;
   const int32_t* timg = tilted ? tilted + (size_t)si * cols : nullptr;
   int k = 0;
+  if (c->max_nodes_per_tree > 1) {  // CvCascadeBoostTree::predict: walk while the node has children
+    int nodeOfs = 0, leafOfs = 0;
+    for (int st = 0; st < c->nstages; st++) {
+      double acc = 0;
+      for (int i = 0; i < c->stage_ntrees[st]; i++, k++) {
+        int idx = 0;
+        do {
+          const int n = nodeOfs + idx;
+          if (c->feature_type == 0) {
+            float nf = normfactor[si];
+            const OrcHaarFeature& f = c->haar[c->node_feature[n]];
+            float val = !nf ? 0.0f : haar_calc(f, f.tilted ? timg : img, step) / nf;
+            idx = val <= c->node_threshold[n] ? c->node_left[n] : c->node_right[n];
+          } else {
+            int code = lbp_calc(c->lbp_rect + 4 * c->node_feature[n], img, step);
+            const int32_t* subset = c->node_subset + (size_t)n * c->subset_size;
+            idx = (subset[code >> 5] & (1 << (code & 31))) ? c->node_left[n] : c->node_right[n];
+          }
+        } while (idx > 0);
+        acc += c->leaves[leafOfs - idx];
+        nodeOfs += c->tree_nnodes[k];
+        leafOfs += c->tree_nnodes[k] + 1;
+      }
+      if (acc < c->stage_threshold[st] - 1e-5f) return 0;
+    }
+    return 1;
+  }
   for (int st = 0; st < c->nstages; st++) {
     double acc = 0;
     for (int i = 0; i < c->stage_ntrees[st]; i++, k++) {

@@ -204,3 +204,26 @@ def test_training_side_cascade_predict(haar_xml, lbp_xml, which):
     assert (got == want).all()
     if which == "haar":
         assert got[-1] == 1 and 0 < got.sum() < len(imgs)
+
+
+@pytest.mark.parametrize("which", ["haar", "haar_tilted", "lbp"])
+def test_training_side_predict_with_trees(tmp_path, which):
+    """CvCascadeBoostTree::predict on trees deeper than stumps (o_cvcascadeboosttree.cpp:16-39): ordered splits go left
+    on `<=`, categorical on a set bit; stage passes on sum >= threshold - 1e-5f."""
+    from tests import cascade_factory as cf
+    from tests.util import frame_natural
+    img = frame_natural(320, 240, 3)
+    wins = np.stack([img[y:y + 24, x:x + 24] for y in range(0, 200, 9) for x in range(0, 280, 11)])
+    xml = cf.lbp_tree_cascade() if which == "lbp" else cf.haar_tree_cascade(wins, with_tilted=(which == "haar_tilted"))
+    path = os.path.join(str(tmp_path), "c.xml")
+    open(path, "w").write(xml)
+    c = cc.CascadeClassifier(path)
+    o = orc.load_cascade_xml(path)
+    imgs = wins[:300]
+    mode = ev.ALL if which == "haar_tilted" else ev.BASIC
+    e = _mk(ev.LBP if which == "lbp" else ev.HAAR, mode, len(imgs))
+    e.setImages(imgs)
+    got = e.predict_cascade(c)
+    s, t, nf = orc.set_images(imgs, want_tilted=(mode == ev.ALL), want_norm=(which != "lbp"))
+    want = np.array([orc.train_predict(o, s, t, nf, i, 24, 24) for i in range(len(imgs))], np.uint8)
+    assert (got == want).all() and 0 < got.sum() < len(imgs)
