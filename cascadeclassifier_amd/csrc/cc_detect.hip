@@ -457,6 +457,8 @@ struct EvalArgs {
   const float* stage_thr;
   const void* stumps1;  // stump tables in STEP-1 / STEP-2 tile coordinates
   const void* stumps2;
+  const void* wstumps1;  // Haar wave phase: per-stage reordered copies (NULL = use stumps1/2)
+  const void* wstumps2;
   int trees;            // cascade has trees deeper than stumps: node tables below, no stump tables
   const void* nodes1;
   const void* nodes2;
@@ -809,6 +811,7 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
   // ---------------- phase W: one wavefront per window, lanes split the stumps ---------------------------------
   {
     const unsigned short* q = s_q + (st & 1) * TILE_WINDOWS;
+    const Stump CC_CONST* wstumps = as_const_table(reinterpret_cast<const Stump*>(STEP == 2 ? A.wstumps2 : A.wstumps1));
     for (int i = wave; i < n; i += EVAL_WAVES) {
       const int id = q[i];
       const int32_t* b = lds + window_base(id);
@@ -819,7 +822,7 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
         if (A.stop_after >= 0 && s2 > A.stop_after) break;
         const int first = stage_first[s2], nt = stage_ntrees[s2];
         double part = 0.;
-        for (int j = lane; j < nt; j += 64) part += stump_vote(b, stumps + first + j, vnf);
+        for (int j = lane; j < nt; j += 64) part += stump_vote(b, wstumps + first + j, vnf);
         total = wave_sum_f64(part);
         if (total < (double)stage_thr[s2]) break;
       }
@@ -983,6 +986,7 @@ struct cc_detector {
   int stop_after = -1;
   int split_stumps = 0;
   DevBuf<HaarStumpDev> d_haar1, d_haar2;
+  DevBuf<HaarStumpDev> d_haar1w, d_haar2w;  // the same stumps dealt to lanes for the wave phase (bank-aware order)
   DevBuf<LbpStumpDev> d_lbp1, d_lbp2;
   DevBuf<HaarNodeDev> d_hnode1, d_hnode2;  // cascades with trees deeper than stumps
   DevBuf<LbpNodeDev> d_lnode1, d_lnode2;
@@ -1098,6 +1102,74 @@ static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) 
     d.left = m.stump_left[i];
     d.right = m.stump_right[i];
   }
+}
+
+// Wave phase: lane l of step k evaluates stump (64 k + l) of the stage, so the 32 lanes of a half-wavefront read 32
+// unrelated LDS words per corner slot (~3.8-way bank conflicts in file order). The stage sums are order-independent
+// when this phase is used, so the stumps of a stage may be dealt to the lanes in any order, and the two '+' and the
+// two '-' corners of a rectangle may swap slots: a greedy pass fills one 32-lane group at a time with the stump
+// (and corner arrangement) that adds the fewest conflict cycles. Returns a reordered copy of the table.
+static std::vector<HaarStumpDev> schedule_for_wave_phase(const Cascade& m, const std::vector<HaarStumpDev>& t) {
+  std::vector<HaarStumpDev> out;
+  out.reserve(t.size());
+  auto variant = [](const HaarStumpDev& s, int v) {  // v: 6 bits, per rect swap of slots (0,3) and of slots (1,2)
+    HaarStumpDev r = s;
+    for (int j = 0; j < 3; j++) {
+      if (v & (1 << (2 * j))) std::swap(r.ofs[j][0], r.ofs[j][3]);
+      if (v & (2 << (2 * j))) std::swap(r.ofs[j][1], r.ofs[j][2]);
+    }
+    return r;
+  };
+  for (size_t s = 0; s < m.stage_ntrees.size(); s++) {
+    const int first = m.stage_first[s], nt = m.stage_ntrees[s];
+    std::vector<char> used((size_t)nt, 0);
+    int left = nt;
+    while (left > 0) {
+      // per slot: how many distinct words each bank already holds in this 32-lane group
+      std::vector<std::vector<int>> words(12 * 32);
+      int mx[12] = {0};
+      for (int lane = 0; lane < 32 && left > 0; lane++) {
+        int best = -1, best_v = 0, best_cost = 1 << 30;
+        int looked = 0;
+        for (int i = 0; i < nt && looked < 48; i++) {  // bounded look-ahead keeps detector creation fast
+          if (used[(size_t)i]) continue;
+          looked++;
+          const HaarStumpDev& c = t[(size_t)first + i];
+          const int nslots = c.nrect == 3 ? 12 : 8;
+          for (int v = 0; v < (c.nrect == 3 ? 64 : 16); v++) {
+            const HaarStumpDev r = variant(c, v);
+            int cost = 0;
+            for (int k = 0; k < nslots; k++) {
+              const int o = r.ofs[k >> 2][k & 3];
+              const std::vector<int>& w = words[(size_t)k * 32 + (o & 31)];
+              const bool present = std::find(w.begin(), w.end(), o) != w.end();
+              const int load = (int)w.size() + (present ? 0 : 1);
+              if (load > mx[k]) cost += load - mx[k];
+            }
+            if (cost < best_cost) {
+              best_cost = cost;
+              best = i;
+              best_v = v;
+              if (cost == 0) break;
+            }
+          }
+          if (best_cost == 0) break;
+        }
+        const HaarStumpDev r = variant(t[(size_t)first + best], best_v);
+        const int nslots = r.nrect == 3 ? 12 : 8;
+        for (int k = 0; k < nslots; k++) {
+          const int o = r.ofs[k >> 2][k & 3];
+          std::vector<int>& w = words[(size_t)k * 32 + (o & 31)];
+          if (std::find(w.begin(), w.end(), o) == w.end()) w.push_back(o);
+          mx[k] = std::max(mx[k], (int)w.size());
+        }
+        out.push_back(r);
+        used[(size_t)best] = 1;
+        left--;
+      }
+    }
+  }
+  return out;
 }
 
 template <int STEP>
@@ -1409,6 +1481,8 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.tiles = P->d_tiles.p;
     A.stumps1 = haar ? (const void*)d->d_haar1.p : (const void*)d->d_lbp1.p;
     A.stumps2 = haar ? (const void*)d->d_haar2.p : (const void*)d->d_lbp2.p;
+    A.wstumps1 = d->d_haar1w.p ? (const void*)d->d_haar1w.p : A.stumps1;
+    A.wstumps2 = d->d_haar2w.p ? (const void*)d->d_haar2w.p : A.stumps2;
     A.trees = d->m.max_nodes_per_tree > 1 ? 1 : 0;
     A.nodes1 = haar ? (const void*)d->d_hnode1.p : (const void*)d->d_lnode1.p;
     A.nodes2 = haar ? (const void*)d->d_hnode2.p : (const void*)d->d_lnode2.p;
@@ -1646,6 +1720,12 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
     build_haar_stumps<2>(d->m, s2);
     CC_HIP(d->d_haar1.upload(s1, d->stream));
     CC_HIP(d->d_haar2.upload(s2, d->stream));
+    if (d->wave_below > 0 && !std::getenv("CCAMD_NO_WAVE_SCHEDULE")) {
+      const std::vector<HaarStumpDev> w1 = schedule_for_wave_phase(d->m, s1), w2 = schedule_for_wave_phase(d->m, s2);
+      CC_HIP(d->d_haar1w.upload(w1, d->stream));
+      CC_HIP(d->d_haar2w.upload(w2, d->stream));
+      CC_HIP(hipStreamSynchronize(d->stream));
+    }
     CC_HIP(hipStreamSynchronize(d->stream));
   } else {
     std::vector<LbpStumpDev> s1, s2;
