@@ -110,6 +110,10 @@ SIGNATURES = {
     "cc_eval_get_sample": (_i, [_vp, _i, _vp, _vp, _vp]),
     "cc_eval_predict_cascade": (_i, [_vp, _vp, _vp, _i, _vp]),
     "cc_eval_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double)]),
+    "cc_negminer_create": (_i, [_vp, _i, _pp]),
+    "cc_negminer_destroy": (None, [_vp]),
+    "cc_negminer_plan": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(_i), C.POINTER(C.c_int64)]),
+    "cc_negminer_run": (_i, [_vp, _vp, _i, _i, _sz, _i, _i, _vp, C.c_int64, C.POINTER(C.c_int64), _vp, _vp, _i, C.POINTER(_i)]),
 }
 
 _lib = None

@@ -921,6 +921,143 @@ __global__ void k_debug_visited(const ScaleDev* __restrict__ sd, int nscales, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Negative mining (training side): one thread per window of the reader's stream; integrals are read from global
+// memory (windows sit half a window apart, there is little to share), geometry -> offsets on the fly because every
+// ladder level has its own row pitch. Arithmetic is the trainer's: value = calc / normfactor, `<=` goes left.
+// ------------------------------------------------------------------------------------------------
+struct MineLevel {
+  int w, h, pitchI, nx, ny;
+  long long int_ofs, img_ofs;
+  long long win_first;
+  int pitch8;
+  int pad;
+};
+struct MineNode {  // a tree node with its feature's geometry
+  int r[3][4];
+  float w[3];
+  int tilted;
+  float thr;
+  int left, right;  // child > 0: node index inside the tree; child <= 0: leaf index -child
+  int subset[8];
+  int pad;
+};
+struct MineArgs {
+  const int32_t* integ;  // channels: 0 sum, 1 sqsum (Haar), 2 tilted (if any)
+  size_t chan_elems;
+  const MineLevel* levels;
+  int n_levels;
+  long long n_windows;
+  int W0, H0, ox, oy, sx, sy;
+  int nstages;
+  const int* stage_first;
+  const int* stage_ntrees;
+  const float* stage_thr;
+  const MineNode* nodes;
+  const int* tree_root;
+  const int* tree_leaf0;
+  const float* leaves;
+  uint8_t* pass;
+};
+
+template <bool HAAR>
+__global__ __launch_bounds__(256) void k_negmine_windows(MineArgs A) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.n_windows) return;
+  int l = 0;
+  while (l + 1 < A.n_levels && A.levels[l + 1].win_first <= i) l++;
+  const MineLevel L = A.levels[l];
+  const int k = (int)(i - L.win_first);
+  const int gy = k / L.nx, gx = k - gy * L.nx;
+  const int x = A.ox + gx * A.sx, y = A.oy + gy * A.sy;
+  const int32_t* sum = A.integ + L.int_ofs;
+  const int32_t* til = A.integ + 2 * A.chan_elems + L.int_ofs;
+  const int P = L.pitchI;
+  const size_t base = (size_t)y * P + x;
+  float nf = 1.f;
+  if (HAAR) {  // calcNormFactor, features.cpp:13-25 (the 4-corner difference of the wrapped squared sums is exact)
+    const unsigned* sq = reinterpret_cast<const unsigned*>(A.integ + A.chan_elems + L.int_ofs);
+    const int nw = A.W0 - 2, nh = A.H0 - 2;
+    const size_t q = base + P + 1;
+    const int vs = sum[q] - sum[q + nw] - sum[q + (size_t)nh * P] + sum[q + (size_t)nh * P + nw];
+    const unsigned vq = sq[q] - sq[q + nw] - sq[q + (size_t)nh * P] + sq[q + (size_t)nh * P + nw];
+    const double area = (double)(nw * nh);
+    nf = (float)sqrt((double)(area * (double)vq - (double)vs * (double)vs));
+  }
+  uint8_t pass = 1;
+  for (int st = 0; st < A.nstages && pass; st++) {
+    double acc = 0;
+    const int first = A.stage_first[st], nt = A.stage_ntrees[st];
+    for (int t = first; t < first + nt; t++) {
+      int idx = 0;
+      const int root = A.tree_root[t];
+      do {
+        const MineNode* n = A.nodes + root + idx;
+        bool go_left;
+        if (HAAR) {
+          const int32_t* b = (n->tilted ? til : sum) + base;
+          float ret = 0.f;
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            if (j == 2 && n->w[2] == 0.0f) break;
+            const int rx = n->r[j][0], ry = n->r[j][1], rw = n->r[j][2], rh = n->r[j][3];
+            int p0, p1, p2, p3;
+            if (!n->tilted) {  // CV_SUM_OFFSETS
+              p0 = rx + P * ry;
+              p1 = rx + rw + P * ry;
+              p2 = rx + P * (ry + rh);
+              p3 = rx + rw + P * (ry + rh);
+            } else {  // CV_TILTED_OFFSETS
+              p0 = rx + P * ry;
+              p1 = rx - rh + P * (ry + rh);
+              p2 = rx + rw + P * (ry + rw);
+              p3 = rx + rw - rh + P * (ry + rw + rh);
+            }
+            const float term = n->w[j] * (float)(b[p0] - b[p1] - b[p2] + b[p3]);
+            ret = j == 0 ? term : ret + term;
+          }
+          const float val = nf == 0.0f ? 0.0f : ret / nf;
+          go_left = val <= n->thr;
+        } else {
+          const int32_t* b = sum + base;
+          int p[16];
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) p[4 * rr + cc] = b[(n->r[0][0] + cc * n->r[0][2]) + P * (n->r[0][1] + rr * n->r[0][3])];
+          const int c = p[5] - p[6] - p[9] + p[10];
+          const int code = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
+                           (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
+                           (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
+                           (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
+          go_left = (n->subset[code >> 5] & (1 << (code & 31))) != 0;
+        }
+        idx = go_left ? n->left : n->right;
+      } while (idx > 0);
+      acc += (double)A.leaves[A.tree_leaf0[t] - idx];
+    }
+    if (acc < (double)A.stage_thr[st]) pass = 0;
+  }
+  A.pass[i] = pass;
+}
+
+// copies the pixels of selected stream windows out of the ladder: one block per window
+__global__ __launch_bounds__(64) void k_negmine_gather(const uint8_t* __restrict__ pyr, const MineLevel* __restrict__ levels, int n_levels,
+                                                       const long long* __restrict__ keep, int W0, int H0, int ox, int oy, int sx, int sy,
+                                                       uint8_t* __restrict__ out) {
+  const long long i = keep[blockIdx.x];
+  int l = 0;
+  while (l + 1 < n_levels && levels[l + 1].win_first <= i) l++;
+  const MineLevel L = levels[l];
+  const int k = (int)(i - L.win_first);
+  const int gy = k / L.nx, gx = k - gy * L.nx;
+  const uint8_t* src = pyr + L.img_ofs + (size_t)(oy + gy * sy) * L.pitch8 + (ox + gx * sx);
+  for (int e = threadIdx.x; e < W0 * H0; e += 64) {
+    const int yy = e / W0, xx = e - yy * W0;
+    out[(size_t)blockIdx.x * W0 * H0 + e] = src[(size_t)yy * L.pitch8 + xx];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 template <class T>
@@ -1024,6 +1161,26 @@ struct cc_detector {
     for (auto& e : pass_done)
       if (e) (void)hipEventDestroy(e);
     if (h_counts) (void)hipHostFree(h_counts);
+  }
+};
+
+struct cc_negminer {
+  Cascade m;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevBuf<MineNode> d_nodes;
+  DevBuf<int> d_stage_first, d_stage_ntrees, d_tree_root, d_tree_leaf0;
+  DevBuf<float> d_stage_thr, d_leaves;
+  // per-image workspace
+  DevBuf<uint8_t> d_src, d_pyr, d_pass, d_pix;
+  DevBuf<int32_t> d_integ, d_hbuf, d_diag;
+  DevBuf<ScaleDev> d_sd;
+  DevBuf<MineLevel> d_levels;
+  DevBuf<int> d_resize_first, d_band_first, d_col_first, d_diag_first, d_tcol_first, d_xofs, d_yofs;
+  DevBuf<uint16_t> d_xw1, d_yw1;
+  DevBuf<long long> d_keep;
+  ~cc_negminer() {
+    if (stream) (void)hipStreamDestroy(stream);
   }
 };
 
@@ -1988,6 +2145,274 @@ cc_status cc_integral_u8(int device, const uint8_t* img, int width, int height, 
                        d_sd.p, 1, d_tcol_first.p);
     CC_HIP(hipGetLastError());
     CC_HIP(hipMemcpy2D(tilted, opitch, d_tilt.p, (size_t)S.pitchI * 4, opitch, height + 1, hipMemcpyDeviceToHost));
+  }
+  return CC_OK;
+}
+
+// ---- negative mining ---------------------------------------------------------------------------------------------
+namespace {
+
+struct MineGeom {
+  int w, h, nx, ny;
+};
+
+// The reader's scale ladder and window grid for one image (imagestorage.cpp:57-126), in its float arithmetic.
+void mine_ladder(int W0, int H0, int cols, int rows, int ox, int oy, std::vector<MineGeom>& out) {
+  out.clear();
+  const float scaleFactor = 1.4142135623730950488016887242097F, stepFactor = 0.5F;
+  float scale = std::max(((float)W0 + ox) / ((float)cols), ((float)H0 + oy) / ((float)rows));
+  int lw = (int)(scale * cols + 0.5F), lh = (int)(scale * rows + 0.5F);
+  for (;;) {
+    MineGeom g{lw, lh, 0, 0};
+    int x = ox;
+    g.nx = 1;
+    while ((int)(x + (1.0F + stepFactor) * W0) < lw) {
+      x += (int)(stepFactor * W0);
+      g.nx++;
+    }
+    int y = oy;
+    g.ny = 1;
+    while ((int)(y + (1.0F + stepFactor) * H0) < lh) {
+      y += (int)(stepFactor * H0);
+      g.ny++;
+    }
+    out.push_back(g);
+    scale *= scaleFactor;
+    if (!(scale <= 1.0F) || out.size() > 64) break;
+    lw = (int)(scale * cols);
+    lh = (int)(scale * rows);
+  }
+}
+
+cc_status mine_check(const cc_negminer* m, int width, int height, int ox, int oy, const char* who) {
+  if (!m) return set_error(CC_ERR_INVALID_ARG, "%s: null miner", who);
+  if (width < 1 || height < 1 || width > 32768 || height > 32768) return set_error(CC_ERR_INVALID_ARG, "%s: bad image size", who);
+  // NegReader::nextImg only accepts offsets with 0 <= ox <= cols - W, 0 <= oy <= rows - H
+  if (ox < 0 || oy < 0 || ox > width - m->m.win_w || oy > height - m->m.win_h)
+    return set_error(CC_ERR_INVALID_ARG, "%s: offset (%d,%d) does not leave room for a %dx%d window in a %dx%d image", who, ox, oy,
+                     m->m.win_w, m->m.win_h, width, height);
+  return CC_OK;
+}
+
+}  // namespace
+
+cc_status cc_negminer_create(const cc_cascade* c, int device, cc_negminer** out) {
+  if (!c || !out) return set_error(CC_ERR_INVALID_ARG, "cc_negminer_create: null argument");
+  *out = nullptr;
+  cc_status st = ensure_device(device);
+  if (st != CC_OK) return st;
+  std::unique_ptr<cc_negminer> m(new cc_negminer());
+  m->m = c->m;
+  m->device = device;
+  CC_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  const Cascade& M = m->m;
+  const bool haar = M.feature_type == CC_FEATURE_HAAR;
+  std::vector<MineNode> nodes(M.node_feature.size());
+  for (size_t i = 0; i < nodes.size(); i++) {
+    MineNode& n = nodes[i];
+    std::memset(&n, 0, sizeof(n));
+    const int fi = M.node_feature[i];
+    if (haar) {
+      bool used = true;
+      for (int j = 0; j < 3; j++) {
+        const float wt = M.haar_weights[(size_t)fi * 3 + j];
+        if (wt == 0.0f) used = false;  // offsets stay 0 from the first zero weight on (haarfeatures.cpp:292-308)
+        if (!used) continue;
+        n.w[j] = wt;
+        for (int k = 0; k < 4; k++) n.r[j][k] = M.haar_rects[(size_t)fi * 12 + j * 4 + k];
+      }
+      n.tilted = M.haar_tilted[fi];
+      n.thr = M.node_threshold[i];
+    } else {
+      for (int k = 0; k < 4; k++) n.r[0][k] = M.lbp_rects[(size_t)fi * 4 + k];
+      for (int j = 0; j < 8; j++) n.subset[j] = M.node_subset[i * 8 + j];
+    }
+    n.left = M.node_left[i];
+    n.right = M.node_right[i];
+  }
+  std::vector<int> sfirst(M.stage_first.begin(), M.stage_first.end()), sn(M.stage_ntrees.begin(), M.stage_ntrees.end());
+  std::vector<int> root(M.tree_first_node.begin(), M.tree_first_node.end()), leaf0(M.tree_first_leaf.begin(), M.tree_first_leaf.end());
+  CC_HIP(m->d_nodes.upload(nodes, m->stream));
+  CC_HIP(m->d_stage_first.upload(sfirst, m->stream));
+  CC_HIP(m->d_stage_ntrees.upload(sn, m->stream));
+  CC_HIP(m->d_stage_thr.upload(M.stage_threshold, m->stream));  // already threshold - 1e-5f (CV_THRESHOLD_EPS)
+  CC_HIP(m->d_tree_root.upload(root, m->stream));
+  CC_HIP(m->d_tree_leaf0.upload(leaf0, m->stream));
+  CC_HIP(m->d_leaves.upload(M.leaves, m->stream));
+  CC_HIP(hipStreamSynchronize(m->stream));
+  *out = m.release();
+  return CC_OK;
+}
+
+void cc_negminer_destroy(cc_negminer* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  delete m;
+}
+
+cc_status cc_negminer_plan(const cc_negminer* m, int width, int height, int ox, int oy, int32_t* lw, int32_t* lh, int32_t* nx,
+                           int32_t* ny, int cap, int* n_levels, int64_t* n_windows) {
+  cc_status st = mine_check(m, width, height, ox, oy, "cc_negminer_plan");
+  if (st != CC_OK) return st;
+  if (!n_levels || !n_windows) return set_error(CC_ERR_INVALID_ARG, "cc_negminer_plan: null output");
+  std::vector<MineGeom> g;
+  mine_ladder(m->m.win_w, m->m.win_h, width, height, ox, oy, g);
+  *n_levels = (int)g.size();
+  *n_windows = 0;
+  for (size_t i = 0; i < g.size(); i++) {
+    *n_windows += (int64_t)g[i].nx * g[i].ny;
+    if ((int)i < cap) {
+      if (lw) lw[i] = g[i].w;
+      if (lh) lh[i] = g[i].h;
+      if (nx) nx[i] = g[i].nx;
+      if (ny) ny[i] = g[i].ny;
+    }
+  }
+  return CC_OK;
+}
+
+cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int height, size_t row_stride, int ox, int oy, uint8_t* pass,
+                          int64_t cap, int64_t* n_windows, uint8_t* pixels, int64_t* keep_index, int max_keep, int* n_keep) {
+  cc_status st = mine_check(m, width, height, ox, oy, "cc_negminer_run");
+  if (st != CC_OK) return st;
+  if (!gray || !pass || !n_windows || row_stride < (size_t)width) return set_error(CC_ERR_INVALID_ARG, "cc_negminer_run: bad argument");
+  if (pixels && (!keep_index || !n_keep || max_keep < 0)) return set_error(CC_ERR_INVALID_ARG, "cc_negminer_run: bad keep buffers");
+  st = ensure_device(m->device);
+  if (st != CC_OK) return st;
+  const Cascade& M = m->m;
+  const int W0 = M.win_w, H0 = M.win_h;
+  const bool haar = M.feature_type == CC_FEATURE_HAAR, tilt = haar && M.has_tilted;
+  std::vector<MineGeom> g;
+  mine_ladder(W0, H0, width, height, ox, oy, g);
+  const int nl = (int)g.size();
+  std::vector<ScaleDev> sd((size_t)nl);
+  std::vector<MineLevel> lv((size_t)nl);
+  std::vector<int> resize_first(nl + 1, 0), band_first(nl + 1, 0), col_first(nl + 1, 0), diag_first(nl + 1, 0), tcol_first(nl + 1, 0);
+  std::vector<int> xofs, yofs;
+  std::vector<uint16_t> xw1, yw1;
+  long long img_ofs = 0, int_ofs = 0, h_ofs = 0, wins = 0;
+  for (int i = 0; i < nl; i++) {
+    ScaleDev& S = sd[(size_t)i];
+    std::memset(&S, 0, sizeof(S));
+    S.w = g[i].w;
+    S.h = g[i].h;
+    if (S.w < W0 + ox || S.h < H0 + oy) return set_error(CC_ERR_INVALID_ARG, "cc_negminer_run: ladder level %d (%dx%d) smaller than window + offset", i, S.w, S.h);
+    S.pitch8 = align_up(S.w, 4);
+    S.pitchI = align_up(S.w + 1, 4);
+    S.img_ofs = img_ofs;
+    S.int_ofs = int_ofs;
+    S.h_ofs = h_ofs;
+    S.nbands = (S.h + INT_BAND - 1) / INT_BAND;
+    S.xtab_ofs = (int)xofs.size();
+    S.ytab_ofs = (int)yofs.size();
+    AxisTaps tx, ty;
+    linear_exact_taps(width, S.w, tx);
+    linear_exact_taps(height, S.h, ty);
+    xofs.insert(xofs.end(), tx.ofs.begin(), tx.ofs.end());
+    xw1.insert(xw1.end(), tx.w1.begin(), tx.w1.end());
+    yofs.insert(yofs.end(), ty.ofs.begin(), ty.ofs.end());
+    yw1.insert(yw1.end(), ty.w1.begin(), ty.w1.end());
+    MineLevel& L = lv[(size_t)i];
+    L.w = S.w;
+    L.h = S.h;
+    L.pitchI = S.pitchI;
+    L.pitch8 = S.pitch8;
+    L.nx = g[i].nx;
+    L.ny = g[i].ny;
+    L.int_ofs = int_ofs;
+    L.img_ofs = img_ofs;
+    L.win_first = wins;
+    L.pad = 0;
+    wins += (long long)g[i].nx * g[i].ny;
+    img_ofs += (long long)align_up(S.pitch8 * S.h, 16);
+    int_ofs += (long long)S.pitchI * (S.h + 1);
+    h_ofs += (long long)S.nbands * S.pitchI;
+    resize_first[i + 1] = resize_first[i] + ((S.pitch8 / 4) * S.h + 255) / 256;
+    band_first[i + 1] = band_first[i] + S.nbands;
+    col_first[i + 1] = col_first[i] + (S.pitchI / 4 + 63) / 64;
+    diag_first[i + 1] = diag_first[i] + (S.w + S.h - 1 + 63) / 64;
+    tcol_first[i + 1] = tcol_first[i] + (S.w + 1 + 63) / 64;
+  }
+  *n_windows = wins;
+  if (wins > cap) return set_error(CC_ERR_BUFFER_TOO_SMALL, "cc_negminer_run: %lld windows, capacity %lld", wins, (long long)cap);
+  hipStream_t s = m->stream;
+  const int nchan = haar ? (tilt ? 3 : 2) : 1;
+  const size_t chan_elems = (size_t)int_ofs, spitch = (size_t)align_up(width, 4);
+  CC_HIP(m->d_sd.upload(sd, s));
+  CC_HIP(m->d_levels.upload(lv, s));
+  CC_HIP(m->d_resize_first.upload(resize_first, s));
+  CC_HIP(m->d_band_first.upload(band_first, s));
+  CC_HIP(m->d_col_first.upload(col_first, s));
+  CC_HIP(m->d_diag_first.upload(diag_first, s));
+  CC_HIP(m->d_tcol_first.upload(tcol_first, s));
+  CC_HIP(m->d_xofs.upload(xofs, s));
+  CC_HIP(m->d_yofs.upload(yofs, s));
+  CC_HIP(m->d_xw1.upload(xw1, s));
+  CC_HIP(m->d_yw1.upload(yw1, s));
+  CC_HIP(m->d_src.ensure(spitch * (size_t)height));
+  CC_HIP(m->d_pyr.ensure((size_t)((img_ofs + 15) & ~15LL)));
+  CC_HIP(m->d_integ.ensure(chan_elems * (size_t)nchan));
+  CC_HIP(m->d_hbuf.ensure(std::max<size_t>((size_t)h_ofs * (size_t)nchan, 4)));
+  CC_HIP(m->d_pass.ensure((size_t)std::max<long long>(wins, 1)));
+  CC_HIP(hipMemcpy2DAsync(m->d_src.p, spitch, gray, row_stride, (size_t)width, (size_t)height, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_resize, dim3(resize_first[nl], 1), dim3(256), 0, s, m->d_src.p, spitch, (size_t)0, width, height, m->d_pyr.p,
+                     (size_t)0, m->d_sd.p, nl, m->d_resize_first.p, m->d_xofs.p, m->d_xw1.p, m->d_yofs.p, m->d_yw1.p);
+  launch_integral(s, haar, m->d_pyr.p, 0, m->d_integ.p, chan_elems, nchan, m->d_hbuf.p, (size_t)h_ofs, m->d_sd.p, nl, m->d_band_first.p,
+                  band_first[nl], m->d_col_first.p, col_first[nl], 1);
+  if (tilt) {
+    CC_HIP(m->d_diag.ensure(chan_elems * 2));
+    hipLaunchKernelGGL(k_diag_sums, dim3(diag_first[nl], 1, 2), dim3(64), 0, s, m->d_pyr.p, (size_t)0, m->d_diag.p, chan_elems, m->d_sd.p, nl,
+                       m->d_diag_first.p);
+    hipLaunchKernelGGL(k_tilted_cols, dim3(tcol_first[nl], 1), dim3(64), 0, s, m->d_pyr.p, (size_t)0, m->d_diag.p, m->d_integ.p, chan_elems,
+                       nchan, 2, m->d_sd.p, nl, m->d_tcol_first.p);
+  }
+  MineArgs A;
+  A.integ = m->d_integ.p;
+  A.chan_elems = chan_elems;
+  A.levels = m->d_levels.p;
+  A.n_levels = nl;
+  A.n_windows = wins;
+  A.W0 = W0;
+  A.H0 = H0;
+  A.ox = ox;
+  A.oy = oy;
+  A.sx = (int)(0.5F * W0);
+  A.sy = (int)(0.5F * H0);
+  A.nstages = (int)M.stage_ntrees.size();
+  A.stage_first = m->d_stage_first.p;
+  A.stage_ntrees = m->d_stage_ntrees.p;
+  A.stage_thr = m->d_stage_thr.p;
+  A.nodes = m->d_nodes.p;
+  A.tree_root = m->d_tree_root.p;
+  A.tree_leaf0 = m->d_tree_leaf0.p;
+  A.leaves = m->d_leaves.p;
+  A.pass = m->d_pass.p;
+  if (wins > 0) {
+    const unsigned nb = (unsigned)((wins + 255) / 256);
+    if (haar)
+      hipLaunchKernelGGL(k_negmine_windows<true>, dim3(nb), dim3(256), 0, s, A);
+    else
+      hipLaunchKernelGGL(k_negmine_windows<false>, dim3(nb), dim3(256), 0, s, A);
+  }
+  CC_HIP(hipGetLastError());
+  if (wins > 0) CC_HIP(hipMemcpyAsync(pass, m->d_pass.p, (size_t)wins, hipMemcpyDeviceToHost, s));
+  CC_HIP(hipStreamSynchronize(s));
+  if (pixels) {
+    std::vector<long long> keep;
+    for (long long i = 0; i < wins && (int)keep.size() < max_keep; i++)
+      if (pass[i]) keep.push_back(i);
+    *n_keep = (int)keep.size();
+    if (!keep.empty()) {
+      const size_t wsz = (size_t)W0 * H0;
+      CC_HIP(m->d_keep.upload(keep, s));
+      CC_HIP(m->d_pix.ensure(keep.size() * wsz));
+      hipLaunchKernelGGL(k_negmine_gather, dim3((unsigned)keep.size()), dim3(64), 0, s, m->d_pyr.p, m->d_levels.p, nl, m->d_keep.p, W0, H0, ox,
+                         oy, A.sx, A.sy, m->d_pix.p);
+      CC_HIP(hipGetLastError());
+      CC_HIP(hipMemcpyAsync(pixels, m->d_pix.p, keep.size() * wsz, hipMemcpyDeviceToHost, s));
+      CC_HIP(hipStreamSynchronize(s));
+      for (size_t i = 0; i < keep.size(); i++) keep_index[i] = keep[i];
+    }
   }
   return CC_OK;
 }

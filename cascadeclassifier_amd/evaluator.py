@@ -149,3 +149,43 @@ class CvFeatureEvaluator:
             self._release()
         except Exception:
             pass
+
+
+class NegativeMiner:
+    """Batched form of the negative branch of CvCascadeClassifier::fillPassedSamples (cascadeclassifier.cpp:329-357):
+    one call runs the reader's whole window stream of one background image (imagestorage.cpp:57-126) through the
+    trained stages on the device."""
+
+    def __init__(self, cascade, device=0):
+        self._m = C.c_void_p()
+        self._cascade = cascade  # keep the model alive
+        L.check(L.lib().cc_negminer_create(cascade._c, device, C.byref(self._m)))
+        inf = cascade.info()
+        self.win = (inf["win_w"], inf["win_h"])
+
+    def plan(self, width, height, ox=0, oy=0):
+        lw, lh, nx, ny = (np.zeros(64, np.int32) for _ in range(4))
+        nl, nw = C.c_int(0), C.c_int64(0)
+        L.check(L.lib().cc_negminer_plan(self._m, width, height, ox, oy, _vp(lw), _vp(lh), _vp(nx), _vp(ny), 64, C.byref(nl), C.byref(nw)))
+        k = nl.value
+        return {"levels": list(zip(lw[:k].tolist(), lh[:k].tolist(), nx[:k].tolist(), ny[:k].tolist())), "n_windows": nw.value}
+
+    def run(self, img, ox=0, oy=0, max_keep=64):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = self.plan(w, h, ox, oy)["n_windows"]
+        flags = np.zeros(max(cap, 1), np.uint8)
+        pix = np.zeros((max(max_keep, 1), self.win[1], self.win[0]), np.uint8)
+        idx = np.zeros(max(max_keep, 1), np.int64)
+        nw, nk = C.c_int64(0), C.c_int(0)
+        L.check(L.lib().cc_negminer_run(self._m, _vp(img), w, h, w, ox, oy, _vp(flags), cap, C.byref(nw), _vp(pix), _vp(idx),
+                                        max_keep, C.byref(nk)))
+        return flags[:nw.value].copy(), pix[:nk.value].copy(), idx[:nk.value].copy()
+
+    def __del__(self):
+        try:
+            if self._m:
+                L.lib().cc_negminer_destroy(self._m)
+                self._m = C.c_void_p()
+        except Exception:
+            pass

@@ -243,6 +243,32 @@ CC_API cc_status cc_eval_predict_cascade(cc_evaluator* e, const cc_cascade* c, c
                                          uint8_t* out);
 CC_API cc_status cc_eval_last_kernel_ms(cc_evaluator* e, double* ms);
 
+/* ============================================================================================
+ * 5. Batched negative mining over a background image.
+ *    Replaces the per-window loop of CvCascadeClassifier::fillPassedSamples for negatives
+ *    (traincascade/lib/src/cascadeclassifier.cpp:329-357): NegReader::get (imagestorage.cpp:90-126, one window of
+ *    the image's sqrt(2) scale ladder at half-window steps) -> featureEvaluator->setImage (haarfeatures.cpp:100-114)
+ *    -> CvCascadeClassifier::predict (cascadeclassifier.cpp:297-306 -> boost.cpp:461-477 ->
+ *    o_cvcascadeboosttree.cpp:16-39). One call enumerates the reader's whole window stream for ONE image
+ *    (NegReader::nextImg, imagestorage.cpp:57-88, has already chosen the image and the offset), builds each
+ *    ladder level and its integral images once, and evaluates the trained stages on every window on the device.
+ *    Training-side arithmetic: norm factor sqrt(area*sqsum - sum^2) as float, value = calc / nf (0 if nf == 0),
+ *    ordered splits go left on `<=`, a stage passes iff sum >= threshold - 1e-5f.
+ * ============================================================================================ */
+typedef struct cc_negminer cc_negminer;
+CC_API cc_status cc_negminer_create(const cc_cascade* trained_stages, int device, cc_negminer** out);
+CC_API void cc_negminer_destroy(cc_negminer* m);
+/* Ladder of one image: level l has size lw[l] x lh[l] and nx[l] x ny[l] window positions (x = ox + i*(win_w/2),
+ * y = oy + j*(win_h/2)); the stream visits level 0 first, rows top to bottom, windows left to right. Host only. */
+CC_API cc_status cc_negminer_plan(const cc_negminer* m, int width, int height, int ox, int oy, int32_t* lw, int32_t* lh,
+                                  int32_t* nx, int32_t* ny, int cap, int* n_levels, int64_t* n_windows);
+/* pass[i] = 1 iff stream window i passes every trained stage (i < *n_windows <= cap). If pixels != NULL the first
+ * min(max_keep, #passing) passing windows are also copied out, win_w*win_h bytes each, in stream order, with their
+ * stream indices in keep_index; *n_keep = how many were written. */
+CC_API cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int height, size_t row_stride, int ox, int oy,
+                                 uint8_t* pass, int64_t cap, int64_t* n_windows, uint8_t* pixels, int64_t* keep_index,
+                                 int max_keep, int* n_keep);
+
 #ifdef __cplusplus
 }
 #endif

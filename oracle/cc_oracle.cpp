@@ -825,4 +825,65 @@ ORC_API int orc_train_predict(const OrcCascade* c, const int32_t* sum, const int
   return 1;
 }
 
+// Negative mining over ONE background image, as the reference does it window by window: NegReader::nextImg has chosen
+// the image and the offset (imagestorage.cpp:57-88); then NegReader::get (imagestorage.cpp:90-126) hands out one window
+// per call and CvCascadeClassifier::fillPassedSamples (cascadeclassifier.cpp:329-357) runs setImage + predict on it.
+// pass[i] = predict result of stream window i; the first max_keep passing windows' pixels / stream indices are returned.
+// Returns the stream length for this image (windows until the reader would move on to the next image).
+ORC_API int64_t orc_negmine_image(const OrcCascade* c, const uint8_t* src, int cols, int rows, int stride, int ox, int oy,
+                                  uint8_t* pass, int64_t cap, uint8_t* pixels, int64_t* keep_index, int max_keep, int* n_keep) {
+  const int W = c->win_w, H = c->win_h;
+  const float scaleFactor = 1.4142135623730950488016887242097F, stepFactor = 0.5F;
+  bool has_tilted = false;
+  if (c->feature_type == 0)
+    for (int i = 0; i < c->nfeatures; i++) has_tilted = has_tilted || c->haar[i].tilted;
+  // nextImg(): point = offset; scale; first resize
+  int px = ox, py = oy;
+  float scale = std::max(((float)W + px) / ((float)cols), ((float)H + py) / ((float)rows));
+  int iw = (int)(scale * cols + 0.5F), ih = (int)(scale * rows + 0.5F);
+  std::vector<uint8_t> img((size_t)iw * ih);
+  orc_resize_linear_exact_u8(src, cols, rows, stride, img.data(), iw, ih, iw);
+  std::vector<uint8_t> win((size_t)W * H);
+  const int ncols = (W + 1) * (H + 1);
+  std::vector<int32_t> sum(ncols), til(ncols);
+  float nf = 0;
+  int64_t n = 0;
+  int kept = 0;
+  for (;;) {
+    // get(): copy the window at `point`
+    for (int y = 0; y < H; y++) std::memcpy(&win[(size_t)y * W], &img[(size_t)(py + y) * iw + px], W);
+    // setImage + predict (haarfeatures.cpp:100-114 / lbpfeatures.cpp:22-28; cascadeclassifier.cpp:297-306)
+    orc_set_images(win.data(), 1, W, H, has_tilted ? 1 : 0, sum.data(), til.data(), c->feature_type == 0 ? &nf : nullptr);
+    const int ok = orc_train_predict(c, sum.data(), has_tilted ? til.data() : nullptr, &nf, 0, W, H);
+    if (n < cap && pass) pass[n] = (uint8_t)ok;
+    if (ok && kept < max_keep && pixels) {
+      std::memcpy(pixels + (size_t)kept * W * H, win.data(), (size_t)W * H);
+      keep_index[kept] = n;
+      kept++;
+    }
+    n++;
+    // advance (imagestorage.cpp:105-124)
+    if ((int)(px + (1.0F + stepFactor) * W) < iw)
+      px += (int)(stepFactor * W);
+    else {
+      px = ox;
+      if ((int)(py + (1.0F + stepFactor) * H) < ih)
+        py += (int)(stepFactor * H);
+      else {
+        py = oy;
+        scale *= scaleFactor;
+        if (scale <= 1.0F) {
+          iw = (int)(scale * cols);
+          ih = (int)(scale * rows);
+          img.assign((size_t)iw * ih, 0);
+          orc_resize_linear_exact_u8(src, cols, rows, stride, img.data(), iw, ih, iw);
+        } else
+          break;  // the reader would call nextImg() here
+      }
+    }
+  }
+  if (n_keep) *n_keep = kept;
+  return n;
+}
+
 ORC_API int orc_version() { return 1; }

@@ -334,3 +334,19 @@ def detect_multiscale(c: Cascade, img: np.ndarray, scale_factor=1.1, min_neighbo
 def train_predict(c: Cascade, s, t, nf, si, W, H) -> int:
     cs = c.c_struct()
     return int(lib().orc_train_predict(C.byref(cs), _p(s), _p(t), _p(nf), si, W, H))
+
+
+def negmine_image(c: Cascade, img: np.ndarray, ox=0, oy=0, max_keep=64):
+    """Reader stream of one background image through setImage + predict. Returns (pass flags, kept pixels, kept indices)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    cs = c.c_struct()
+    cap = 1 << 22
+    flags = np.zeros(cap, np.uint8)
+    pix = np.zeros((max(max_keep, 1), c.win_h, c.win_w), np.uint8)
+    idx = np.zeros(max(max_keep, 1), np.int64)
+    nk = C.c_int(0)
+    lib().orc_negmine_image.restype = C.c_int64
+    n = lib().orc_negmine_image(C.byref(cs), _p(img), w, h, w, int(ox), int(oy), _p(flags), C.c_int64(cap), _p(pix), _p(idx),
+                                int(max_keep), C.byref(nk))
+    return flags[:n].copy(), pix[:nk.value].copy(), idx[:nk.value].copy()

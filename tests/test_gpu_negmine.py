@@ -1,0 +1,83 @@
+"""Batched negative mining (cc_negminer_*) against the reference's window-by-window loop as restated by the oracle
+(NegReader::get + setImage + CvCascadeClassifier::predict; imagestorage.cpp:57-126, cascadeclassifier.cpp:329-357):
+identical pass flags for every window of the reader's stream, identical pixels for the accepted windows."""
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+
+import cascadeclassifier_amd as cc
+from oracle import oracle as orc
+from tests import cascade_factory as cf
+from tests.util import frame_natural, frame_uniform
+
+
+def _truncated(path, n, tmp):
+    tree = ET.parse(path)
+    casc = list(tree.getroot())[0]
+    stages = casc.find("stages")
+    for s in [s for s in stages if s.tag == "_"][n:]:
+        stages.remove(s)
+    casc.find("stageNum").text = str(n)
+    out = os.path.join(tmp, f"trunc{n}.xml")
+    tree.write(out)
+    return out
+
+
+def _reference_negative():  # test_integration.cpp:59-64
+    r, c = np.mgrid[0:128, 0:256]
+    return ((r * 7 + c * 13) & 0xFF).astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_plan_matches_reader_stream_length(haar_xml):
+    """The ladder / window census equals the length of the oracle's literal reader loop."""
+    o = orc.load_cascade_xml(haar_xml)
+    m = cc.NegativeMiner(cc.CascadeClassifier(haar_xml))
+    for (w, h, ox, oy) in [(256, 128, 0, 0), (256, 128, 5, 3), (100, 75, 0, 0), (640, 480, 23, 23), (24, 24, 0, 0), (31, 200, 7, 0)]:
+        flags, _, _ = orc.negmine_image(o, frame_uniform(w, h, 1), ox, oy, max_keep=0)
+        assert m.plan(w, h, ox, oy)["n_windows"] == len(flags)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["haar3", "haar6", "lbp4", "lbp_full", "haar_tilted", "haar_trees", "lbp_trees"])
+def test_negative_mining_matches_reader_loop(tmp_path, haar_xml, lbp_xml, kind):
+    tmp = str(tmp_path)
+    calib = frame_natural(320, 240, 3)
+    wins = np.stack([calib[y:y + 24, x:x + 24] for y in range(0, 200, 9) for x in range(0, 280, 11)])
+    if kind.startswith("haar") and kind[4:].isdigit():
+        path = _truncated(haar_xml, int(kind[4:]), tmp)
+    elif kind == "lbp4":
+        path = _truncated(lbp_xml, 4, tmp)
+    elif kind == "lbp_full":
+        path = lbp_xml
+    else:
+        xml = {"haar_tilted": lambda: cf.tilted_stump_cascade(wins), "haar_trees": lambda: cf.haar_tree_cascade(wins, with_tilted=True),
+               "lbp_trees": cf.lbp_tree_cascade}[kind]()
+        path = os.path.join(tmp, kind + ".xml")
+        open(path, "w").write(xml)
+    o = orc.load_cascade_xml(path)
+    c = cc.CascadeClassifier(path)
+    assert not c.empty(), getattr(c, "load_error", "")
+    m = cc.NegativeMiner(c)
+    images = [(_reference_negative(), 0, 0), (frame_natural(333, 211, 41), 5, 2), (frame_uniform(100, 64, 42), 23, 23),
+              (frame_natural(640, 480, 43), 0, 17)]
+    total_pass = 0
+    for img, ox, oy in images:
+        want_f, want_p, want_i = orc.negmine_image(o, img, ox, oy, max_keep=40)
+        got_f, got_p, got_i = m.run(img, ox, oy, max_keep=40)
+        assert got_f.shape == want_f.shape and (got_f == want_f).all(), f"{(got_f != want_f).sum()} of {len(want_f)} windows differ"
+        assert (got_i == want_i).all() and (got_p == want_p).all()
+        total_pass += int(want_f.sum())
+    if kind not in ("lbp_full",):
+        assert total_pass > 0
+
+
+@pytest.mark.gpu
+def test_negative_miner_argument_checks(haar_xml):
+    m = cc.NegativeMiner(cc.CascadeClassifier(haar_xml))
+    with pytest.raises(cc.CascadeError):
+        m.run(frame_uniform(64, 64, 1), ox=50, oy=0)  # offset leaves no room for the window (nextImg would skip it)
+    with pytest.raises(cc.CascadeError):
+        m.run(frame_uniform(20, 64, 1))
