@@ -75,6 +75,9 @@ class CvFeatureEvaluator {  // traincascade_features.h:155-188
   void setImages(const uchar* imgs, int n, int first_idx, const uchar* labels);
   // out[(fi - fiBegin) * nSamples + s] = (*this)(fi, sampleIdx ? sampleIdx[s] : s)
   void calcBatch(int fiBegin, int fiEnd, const int* sampleIdx, int nSamples, float* out) const;
+  // values (optional) + per-feature argsort of samples 0..nSamples-1: the rows precalculate() stores in `buf`
+  // (unsigned short when sample_count < 65536, else int; o_cvcascadeboosttraindata.cpp:250-251,490-556)
+  void calcBatchSorted(int fiBegin, int fiEnd, int nSamples, float* vals, void* sortedIdx, bool idx16) const;
   cc_evaluator* handle() const { return h; }
 
  protected:

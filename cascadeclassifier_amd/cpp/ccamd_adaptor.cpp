@@ -226,6 +226,10 @@ void CvFeatureEvaluator::calcBatch(int fiBegin, int fiEnd, const int* sampleIdx,
   check(cc_eval_calc_batch(h, fiBegin, fiEnd, sampleIdx, nSamples, out, 0), "CvFeatureEvaluator::calcBatch");
 }
 
+void CvFeatureEvaluator::calcBatchSorted(int fiBegin, int fiEnd, int nSamples, float* vals, void* sortedIdx, bool idx16) const {
+  check(cc_eval_calc_batch_sorted(h, fiBegin, fiEnd, nSamples, vals, sortedIdx, idx16 ? 2 : 4), "CvFeatureEvaluator::calcBatchSorted");
+}
+
 float CvFeatureEvaluator::cachedValue(int featureIdx, int sampleIdx) const {
   RowCache& rc = g_row;
   if (rc.owner != this || rc.generation != generation || rc.fi != featureIdx) {

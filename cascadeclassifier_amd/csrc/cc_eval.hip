@@ -8,6 +8,7 @@
 // TRANSPOSED into LDS ([integral entry][sample]) so that a wavefront's lanes (samples) hit distinct banks, and writes
 // out[(fi - fi_begin) * n_samples + s] with the sample index fastest (coalesced row segments).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdlib>
@@ -580,6 +581,66 @@ cc_status cc_eval_calc_batch(cc_evaluator* e, int fi_begin, int fi_end, const in
   CC_HIP(hipStreamSynchronize(e->stream));
   float ms = 0;
   if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_ms = ms;
+  return CC_OK;
+}
+
+namespace ccamd {
+__global__ void k_iota_rows(int* __restrict__ v, size_t total, int n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) v[i] = (int)(i % (size_t)n);
+}
+__global__ void k_narrow_u16(const int* __restrict__ in, unsigned short* __restrict__ out, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) out[i] = (unsigned short)in[i];
+}
+}  // namespace ccamd
+
+cc_status cc_eval_calc_batch_sorted(cc_evaluator* e, int fi_begin, int fi_end, int n_samples, float* vals, void* idx, int idx_bytes) {
+  if (!e || !idx) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_batch_sorted: null argument");
+  if (fi_begin < 0 || fi_end > e->nfeat || fi_begin > fi_end)
+    return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc_batch_sorted: features [%d, %d) out of range (%d)", fi_begin, fi_end, e->nfeat);
+  if (n_samples < 0 || n_samples > e->max_samples) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc_batch_sorted: n_samples %d out of range", n_samples);
+  if (idx_bytes != 2 && idx_bytes != 4) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_batch_sorted: idx_bytes must be 2 or 4");
+  if (idx_bytes == 2 && n_samples > 65536) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_batch_sorted: 16-bit indices need n_samples <= 65536");
+  cc_status st = eval_device(e);
+  if (st != CC_OK) return st;
+  const int nf = fi_end - fi_begin;
+  if (nf == 0 || n_samples == 0) return CC_OK;
+  std::lock_guard<std::mutex> lk(e->mu);
+  const bool haar = e->type == CC_FEATURE_HAAR;
+  const size_t total = (size_t)nf * n_samples;
+  if (total > (size_t)INT32_MAX) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_batch_sorted: block too large (%zu values); use smaller feature ranges", total);
+  EBuf<float> keys_out;
+  EBuf<int> iota, sorted, offsets;
+  EBuf<unsigned short> narrow;
+  EBuf<char> temp;
+  CC_HIP(e->d_out.ensure(total));
+  CC_HIP(keys_out.ensure(total));
+  CC_HIP(iota.ensure(total));
+  CC_HIP(sorted.ensure(total));
+  CC_HIP(offsets.ensure((size_t)nf + 1));
+  st = launch_batch(e, haar, haar ? (const void*)e->d_haar.p : (const void*)e->d_lbp.p, fi_begin, fi_end, nullptr, n_samples, e->d_out.p, 1);
+  if (st != CC_OK) return st;
+  std::vector<int> off((size_t)nf + 1);
+  for (int i = 0; i <= nf; i++) off[(size_t)i] = i * n_samples;
+  CC_HIP(hipMemcpyAsync(offsets.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_iota_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, iota.p, total, n_samples);
+  size_t temp_bytes = 0;
+  CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
+                                                     offsets.p, offsets.p + 1, 0, 32, e->stream));
+  CC_HIP(temp.ensure(std::max<size_t>(temp_bytes, 1)));
+  // radix sort is stable: equal values keep increasing sample order
+  CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(temp.p, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
+                                                     offsets.p, offsets.p + 1, 0, 32, e->stream));
+  if (idx_bytes == 2) {
+    CC_HIP(narrow.ensure(total));
+    hipLaunchKernelGGL(k_narrow_u16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, sorted.p, narrow.p, total);
+    CC_HIP(hipMemcpyAsync(idx, narrow.p, total * 2, hipMemcpyDeviceToHost, e->stream));
+  } else
+    CC_HIP(hipMemcpyAsync(idx, sorted.p, total * 4, hipMemcpyDeviceToHost, e->stream));
+  if (vals) CC_HIP(hipMemcpyAsync(vals, e->d_out.p, total * 4, hipMemcpyDeviceToHost, e->stream));
+  CC_HIP(hipGetLastError());
+  CC_HIP(hipStreamSynchronize(e->stream));
   return CC_OK;
 }
 

@@ -77,6 +77,16 @@ class CvFeatureEvaluator:
         L.check(L.lib().cc_eval_calc_batch(self._e, int(fi_begin), int(fi_end), _vp(idx), ns, _vp(out), 0))
         return out
 
+    def calc_batch_sorted(self, fi_begin, fi_end, n_samples=None, idx_bytes=None):
+        """Values and per-feature argsort of the samples (the sorted-index half of precalculate)."""
+        ns = self.maxSampleCount if n_samples is None else n_samples
+        if idx_bytes is None:
+            idx_bytes = 2 if ns < 65536 else 4  # is_buf_16u, o_cvcascadeboosttraindata.cpp:250-251
+        vals = np.empty((fi_end - fi_begin, ns), np.float32)
+        idx = np.empty((fi_end - fi_begin, ns), np.uint16 if idx_bytes == 2 else np.int32)
+        L.check(L.lib().cc_eval_calc_batch_sorted(self._e, int(fi_begin), int(fi_end), ns, _vp(vals), _vp(idx), idx_bytes))
+        return vals, idx
+
     def calc_batch_device(self, fi_begin, fi_end, out_ptr, sample_idx=None, n_samples=None):
         idx = None if sample_idx is None else np.ascontiguousarray(sample_idx, np.int32)
         ns = len(idx) if idx is not None else (self.maxSampleCount if n_samples is None else n_samples)

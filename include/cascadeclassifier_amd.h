@@ -219,6 +219,15 @@ CC_API cc_status cc_eval_calc(cc_evaluator* e, int fi, int si, float* out);
  * out_on_device != 0 (then it is memory of the evaluator's device). */
 CC_API cc_status cc_eval_calc_batch(cc_evaluator* e, int fi_begin, int fi_end, const int32_t* sample_idx, int n_samples,
                                     float* out, int out_on_device);
+/* cc_eval_calc_batch plus, per feature, the argsort of the samples by value: the "sorted index" half of
+ * CvCascadeBoostTrainData::precalculate (FeatureValAndIdxPrecalc / FeatureIdxOnlyPrecalc,
+ * o_cvcascadeboosttraindata.cpp:490-556: `buf` rows of unsigned short when sample_count < 65536, else int).
+ * idx[(fi - fi_begin) * n_samples + k] = index of the sample with the k-th smallest value of feature fi; equal values
+ * keep increasing sample order (the reference's std::sort leaves their order unspecified). idx_bytes is 2 or 4
+ * (2 requires n_samples <= 65536). vals (float[(fi_end - fi_begin) * n_samples], unsorted, as cc_eval_calc_batch) may be
+ * NULL. Host outputs. Samples are 0..n_samples-1. */
+CC_API cc_status cc_eval_calc_batch_sorted(cc_evaluator* e, int fi_begin, int fi_end, int n_samples, float* vals, void* idx,
+                                           int idx_bytes);
 /* Feature::calc (un-normalised) of caller-supplied Haar features on stored samples: the shape of the reference KATs
  * test_features.cpp:462-560. feats: n x {tilted, rects[3][4], weights[3]} as below. */
 typedef struct cc_haar_feature {

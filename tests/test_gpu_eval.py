@@ -227,3 +227,37 @@ def test_training_side_predict_with_trees(tmp_path, which):
     s, t, nf = orc.set_images(imgs, want_tilted=(mode == ev.ALL), want_norm=(which != "lbp"))
     want = np.array([orc.train_predict(o, s, t, nf, i, 24, 24) for i in range(len(imgs))], np.uint8)
     assert (got == want).all() and 0 < got.sum() < len(imgs)
+
+
+@pytest.mark.parametrize("ftype", [ev.HAAR, ev.LBP])
+def test_sorted_index_precalc(ftype):
+    """FeatureValAndIdxPrecalc (o_cvcascadeboosttraindata.cpp:522-562): values + per-feature argsort of the samples.
+    Ties are ordered by sample index here (std::sort in the reference leaves them unspecified): compare with a stable
+    argsort of the oracle's values."""
+    imgs = _samples(300, 9)
+    imgs[10] = imgs[11] = imgs[12]  # identical samples: tied values in every row
+    imgs[20] = 7                    # flat: Haar values 0
+    e = _mk(ftype, ev.BASIC, 300)
+    e.setImages(imgs)
+    n = e.getNumFeatures()
+    a, b = n // 3, n // 3 + 700
+    vals, idx = e.calc_batch_sorted(a, b)
+    assert idx.dtype == np.uint16 and vals.shape == idx.shape == (700, 300)
+    if ftype == ev.HAAR:
+        s, t, nf = orc.set_images(imgs)
+        want = orc.haar_eval_batch(orc.haar_catalog(24, 24, 0), a, b, s, t, nf, 24, 24)
+    else:
+        s, _, _ = orc.set_images(imgs, want_norm=False)
+        want = orc.lbp_eval_batch(orc.lbp_catalog(24, 24), a, b, s, 24, 24)
+    assert (vals.view(np.uint32) == want.view(np.uint32)).all()
+    # -0.0 and +0.0 compare equal in the reference's comparator; normalise before the stable reference argsort
+    ref = np.argsort(want + np.float32(0.0), axis=1, kind="stable")
+    got_sorted = np.take_along_axis(want, idx.astype(np.int64), axis=1)
+    assert (np.diff(got_sorted, axis=1) >= 0).all()          # non-decreasing values
+    assert (np.sort(idx, axis=1) == np.arange(300)).all()    # a permutation of the samples
+    same = (idx == ref).all(axis=1)
+    # rows may differ from the stable order only where a row holds both -0.0 and +0.0 (radix order separates them)
+    for r in np.nonzero(~same)[0]:
+        assert (want[r] == 0).sum() >= 2 and np.signbit(want[r][want[r] == 0]).any()
+    _, idx32 = e.calc_batch_sorted(a, a + 5, idx_bytes=4)
+    assert idx32.dtype == np.int32 and (idx32 == idx[:5]).all()
