@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--min-neighbors", type=int, default=3)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--device-only", action="store_true", help="time the device pipeline only (no copy-back/grouping)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                                                      "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import torch
@@ -75,17 +77,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     W, H, B = args.width, args.height, args.frames
     frames_host = make_frames(B, W, H, seed0=rank * B)
     frames = torch.from_numpy(frames_host).to(dev)  # resident in HBM before the timed region
-    clf = cc.CascadeClassifier(args.cascade, device=local_rank, max_batch=B)
+    clf = cc.CascadeClassifier(args.cascade, device=dev_index, max_batch=B)
     assert not clf.empty(), getattr(clf, "load_error", "")
     inf = clf.info()
     plan = cc.scale_plan(inf["win_w"], inf["win_h"], W, H, args.scale_factor)
@@ -100,7 +107,7 @@ def main():
             return None
         rects = clf.detect_batch(None, args.scale_factor, args.min_neighbors, device_ptr=frames.data_ptr(), shape=(B, H, W))
         if world > 1:
-            rects = gather_detections(rects, device=dev)
+            rects = gather_detections(rects, device=comm_dev)
         return rects
 
     def sync():
@@ -122,7 +129,7 @@ def main():
     tm = clf.timings(reset=True)
     clf.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
