@@ -1,8 +1,10 @@
 // Cascade model: reader of the new-format cascade.xml (the format CvCascadeClassifier::save writes,
 // traincascade/lib/src/cascadeclassifier.cpp:439-456 with the tags of cascadeclassifier.h:27-73) and the
 // C ABI accessors of section 1 of include/cascadeclassifier_amd.h. Host code only.
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -264,6 +266,18 @@ cc_status cascade_from_xml(const XmlNode& root, Cascade& c) {
 
 using namespace ccamd;
 
+namespace {
+// FileStorage prints float reals with "%.8e" and integral reals as "2." (8 significant digits + exponent round-trip a float)
+std::string real_text(float v) {
+  char b[64];
+  if (v == (float)(long long)v && v > -1e9f && v < 1e9f)
+    snprintf(b, sizeof(b), "%lld.", (long long)v);
+  else
+    snprintf(b, sizeof(b), "%.8e", (double)v);
+  return b;
+}
+}  // namespace
+
 extern "C" {
 
 cc_status cc_cascade_load_xml_mem(const char* text, size_t len, cc_cascade** out) {
@@ -294,6 +308,119 @@ cc_status cc_cascade_load_xml(const char* path, cc_cascade** out) {
 }
 
 void cc_cascade_destroy(cc_cascade* c) { delete c; }
+
+cc_status cc_cascade_save_xml(const cc_cascade* c, const char* path) {
+  if (!c || !path) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_save_xml: null argument");
+  const Cascade& m = c->m;
+  const bool haar = m.feature_type == CC_FEATURE_HAAR;
+  std::ostringstream o;
+  int max_weak = 0;
+  for (int n : m.stage_ntrees) max_weak = std::max(max_weak, n);
+  o << "<?xml version=\"1.0\"?>\n<opencv_storage>\n<cascade>\n";
+  o << "  <stageType>BOOST</stageType>\n  <featureType>" << (haar ? "HAAR" : "LBP") << "</featureType>\n";
+  o << "  <height>" << m.win_h << "</height>\n  <width>" << m.win_w << "</width>\n";
+  o << "  <stageParams>\n    <maxWeakCount>" << max_weak << "</maxWeakCount></stageParams>\n";
+  o << "  <featureParams>\n    <maxCatCount>" << m.max_cat_count << "</maxCatCount>\n    <featSize>1</featSize></featureParams>\n";
+  o << "  <stageNum>" << m.stage_ntrees.size() << "</stageNum>\n  <stages>\n";
+  for (size_t s = 0; s < m.stage_ntrees.size(); s++) {
+    // the model keeps (float)stageThreshold - 1e-5f; write back a value that parses to the same float after the
+    // reader subtracts the epsilon again: search the neighbourhood of thr + 1e-5f
+    const float stored = m.stage_threshold[s];
+    float t = stored + 1e-5f;
+    for (int k = 0; k < 64 && (float)(t - 1e-5f) != stored; k++) t = (float)(t - 1e-5f) < stored ? std::nextafterf(t, INFINITY) : std::nextafterf(t, -INFINITY);
+    if ((float)(t - 1e-5f) != stored) return set_error(CC_ERR_UNSUPPORTED, "cc_cascade_save_xml: stage threshold %zu has no float pre-image", s);
+    o << "    <_>\n      <maxWeakCount>" << m.stage_ntrees[s] << "</maxWeakCount>\n      <stageThreshold>" << real_text(t)
+      << "</stageThreshold>\n      <weakClassifiers>\n";
+    for (int i = 0; i < m.stage_ntrees[s]; i++) {
+      const size_t t_i = (size_t)m.stage_first[s] + i;
+      const int n0 = m.tree_first_node[t_i], nn = m.tree_nnodes[t_i], l0 = m.tree_first_leaf[t_i];
+      o << "        <_>\n          <internalNodes>\n           ";
+      for (int k = 0; k < nn; k++) {
+        o << " " << m.node_left[n0 + k] << " " << m.node_right[n0 + k] << " " << m.node_feature[n0 + k];
+        if (m.subset_size > 0)
+          for (int j = 0; j < m.subset_size; j++) o << " " << m.node_subset[(size_t)(n0 + k) * m.subset_size + j];
+        else
+          o << " " << real_text(m.node_threshold[n0 + k]);
+      }
+      o << "</internalNodes>\n          <leafValues>\n           ";
+      for (int k = 0; k < nn + 1; k++) o << " " << real_text(m.leaves[l0 + k]);
+      o << "</leafValues></_>\n";
+    }
+    o << "      </weakClassifiers></_>\n";
+  }
+  o << "  </stages>\n  <features>\n";
+  const int nf = m.n_features();
+  for (int f = 0; f < nf; f++) {
+    if (haar) {
+      o << "    <_>\n      <rects>\n";
+      for (int j = 0; j < 3; j++) {
+        const int32_t* r = &m.haar_rects[(size_t)f * 12 + j * 4];
+        const float w = m.haar_weights[(size_t)f * 3 + j];
+        if (j > 0 && r[2] == 0 && w == 0.0f) break;  // Feature::write stops at the first rect of zero width
+        o << "        <_>\n          " << r[0] << " " << r[1] << " " << r[2] << " " << r[3] << " " << real_text(w) << "</_>\n";
+      }
+      o << "      </rects>\n      <tilted>" << (m.haar_tilted[f] ? 1 : 0) << "</tilted></_>\n";
+    } else {
+      const int32_t* r = &m.lbp_rects[(size_t)f * 4];
+      o << "    <_>\n      <rect>\n        " << r[0] << " " << r[1] << " " << r[2] << " " << r[3] << "</rect></_>\n";
+    }
+  }
+  o << "  </features>\n</cascade>\n</opencv_storage>\n";
+  std::ofstream f(path, std::ios::binary);
+  if (!f) return set_error(CC_ERR_IO, "cannot open '%s' for writing", path);
+  const std::string text = o.str();
+  f.write(text.data(), (std::streamsize)text.size());
+  if (!f) return set_error(CC_ERR_IO, "write to '%s' failed", path);
+  return CC_OK;
+}
+
+cc_status cc_vec_read(const char* path, int32_t* count, int32_t* vec_size, uint8_t* pixels, int cap_samples) {
+  if (!path || !count || !vec_size) return set_error(CC_ERR_INVALID_ARG, "cc_vec_read: null argument");
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return set_error(CC_ERR_IO, "cannot open '%s'", path);
+  int32_t hdr[2];
+  int16_t mm[2];
+  f.read(reinterpret_cast<char*>(hdr), 8);
+  f.read(reinterpret_cast<char*>(mm), 4);
+  if (!f || hdr[0] < 0 || hdr[1] <= 0) return set_error(CC_ERR_PARSE, "wrong file format for %s", path);
+  f.seekg(0, std::ios::end);
+  const long long fsize = (long long)f.tellg();
+  if (12 + (long long)hdr[0] * (1 + 2LL * hdr[1]) > fsize)
+    return set_error(CC_ERR_PARSE, "%s: header promises %d samples of %d values but the file has %lld bytes", path, hdr[0], hdr[1], fsize);
+  f.seekg(12, std::ios::beg);
+  *count = hdr[0];
+  *vec_size = hdr[1];
+  if (!pixels) return CC_OK;
+  std::vector<int16_t> rec((size_t)hdr[1]);
+  const int n = std::min(hdr[0], std::max(cap_samples, 0));
+  for (int i = 0; i < n; i++) {
+    char zero;
+    f.read(&zero, 1);
+    f.read(reinterpret_cast<char*>(rec.data()), (std::streamsize)rec.size() * 2);
+    if (!f) return set_error(CC_ERR_PARSE, "%s: sample %d is truncated (vec-file has incorrect structure)", path, i);
+    for (int k = 0; k < hdr[1]; k++) pixels[(size_t)i * hdr[1] + k] = (uint8_t)rec[(size_t)k];
+  }
+  return CC_OK;
+}
+
+cc_status cc_vec_write(const char* path, const uint8_t* pixels, int count, int width, int height) {
+  if (!path || (count > 0 && !pixels) || count < 0 || width < 1 || height < 1) return set_error(CC_ERR_INVALID_ARG, "cc_vec_write: bad argument");
+  std::ofstream f(path, std::ios::binary);
+  if (!f) return set_error(CC_ERR_IO, "cannot open '%s' for writing", path);
+  const int32_t hdr[2] = {count, width * height};
+  const int16_t mm[2] = {0, 0};
+  f.write(reinterpret_cast<const char*>(hdr), 8);
+  f.write(reinterpret_cast<const char*>(mm), 4);
+  std::vector<int16_t> rec((size_t)width * height);
+  for (int i = 0; i < count; i++) {
+    const char zero = 0;
+    for (size_t k = 0; k < rec.size(); k++) rec[k] = pixels[(size_t)i * rec.size() + k];
+    f.write(&zero, 1);
+    f.write(reinterpret_cast<const char*>(rec.data()), (std::streamsize)rec.size() * 2);
+  }
+  if (!f) return set_error(CC_ERR_IO, "write to '%s' failed", path);
+  return CC_OK;
+}
 
 cc_status cc_cascade_info_get(const cc_cascade* c, cc_cascade_info* info) {
   if (!c || !info) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_info_get: null argument");

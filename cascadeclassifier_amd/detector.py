@@ -114,6 +114,10 @@ class CascadeClassifier:
     def empty(self) -> bool:
         return not self._c
 
+    def save(self, filename: str):
+        """Write the model back as a new-format cascade.xml (CvCascadeClassifier::save layout)."""
+        L.check(L.lib().cc_cascade_save_xml(self._c, filename.encode()))
+
     def info(self) -> dict:
         ci = L.CascadeInfo()
         L.check(L.lib().cc_cascade_info_get(self._c, C.byref(ci)))
@@ -257,3 +261,18 @@ class CascadeClassifier:
             self._release()
         except Exception:
             pass
+
+
+def vec_read(path: str, max_samples: int | None = None) -> np.ndarray:
+    """Samples of a .vec file as (n, width*height) uint8 (PosReader semantics, imagestorage.cpp:138-182)."""
+    cnt, vs = C.c_int32(0), C.c_int32(0)
+    L.check(L.lib().cc_vec_read(path.encode(), C.byref(cnt), C.byref(vs), None, 0))
+    n = cnt.value if max_samples is None else min(cnt.value, max_samples)
+    out = np.zeros((max(n, 1), vs.value), np.uint8)
+    L.check(L.lib().cc_vec_read(path.encode(), C.byref(cnt), C.byref(vs), _vp(out), n))
+    return out[:n]
+
+
+def vec_write(path: str, samples: np.ndarray, width: int, height: int):
+    samples = np.ascontiguousarray(samples, np.uint8).reshape(-1, width * height)
+    L.check(L.lib().cc_vec_write(path.encode(), _vp(samples), len(samples), width, height))

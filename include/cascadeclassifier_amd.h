@@ -90,6 +90,19 @@ CC_API cc_status cc_cascade_stumps(const cc_cascade* c, const int32_t** feature_
 CC_API cc_status cc_cascade_features(const cc_cascade* c, const int32_t** rects, const float** weights,
                                      const int32_t** tilted);
 
+/* Writes the model back as a new-format cascade.xml (the layout of CvCascadeClassifier::save,
+ * traincascade/lib/src/cascadeclassifier.cpp:439-456; stages boost.cpp:520-532, trees o_cvcascadeboosttree.cpp:41-93,
+ * features haarfeatures.cpp:311-320 / lbpfeatures.cpp:65-68). Reading the written file yields an identical model. */
+CC_API cc_status cc_cascade_save_xml(const cc_cascade* c, const char* path);
+
+/* .vec sample files (positives of the trainer): header int32 count, int32 width*height, 2 x int16 0; per sample one zero
+ * byte + width*height int16 pixels. Reader: CvCascadeImageReader::PosReader (traincascade/lib/src/imagestorage.cpp:138-182);
+ * writer: icvWriteVecHeader / icvWriteVecSample (tools/createsamples/utility.cpp:128-152). Host-side file IO.
+ * cc_vec_read: *count / *vec_size are always set when the header parses; pixels (count * vec_size bytes, may be NULL to
+ * query the sizes) receives at most cap_samples samples, each pixel narrowed to 8 bits as the reader does. */
+CC_API cc_status cc_vec_read(const char* path, int32_t* count, int32_t* vec_size, uint8_t* pixels, int cap_samples);
+CC_API cc_status cc_vec_write(const char* path, const uint8_t* pixels, int count, int width, int height);
+
 /* ============================================================================================
  * 2. Detector.
  *    Replaces: cv::CascadeClassifier::detectMultiScale(gray, objects, scaleFactor, minNeighbors, flags,
