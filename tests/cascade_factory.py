@@ -137,3 +137,19 @@ def lbp_tree_cascade(seed=31, stage_sizes=(3, 4, 5, 6)):
             t += 1
         stages.append((np.float32(-0.1 * nw), weaks))
     return lbp_xml(rects, stages)
+
+
+def lbp_stump_cascade(W, H, seed=41, stage_sizes=(3, 4, 5)):
+    """LBP stump cascade for an arbitrary window size (exercises tile geometry other than 24x24)."""
+    rng = np.random.default_rng(seed)
+    cat = orc.lbp_catalog(W, H)
+    n = sum(stage_sizes)
+    rects = cat[rng.choice(len(cat), n, replace=False)]
+    stages, fi = [], 0
+    for nw in stage_sizes:
+        weaks = []
+        for _ in range(nw):
+            weaks.append(([(0, -1, fi, rng.integers(-2**31, 2**31, 8))], rng.uniform(-1, 1, 2).astype(np.float32)))
+            fi += 1
+        stages.append((np.float32(-0.2 * nw), weaks))
+    return lbp_xml(rects, stages, W=W, H=H)

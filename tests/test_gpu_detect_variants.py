@@ -76,3 +76,12 @@ def test_cyclic_tree_is_refused():
     bad = cf.haar_xml(orc.haar_catalog(24, 24, 0)[:2], [(np.float32(0), [([(1, -1, 0, np.float32(0)), (1, -2, 1, np.float32(0))], [0.1, 0.2, 0.3])])])
     p = cc.CascadeClassifier()
     assert not p.load_from_string(bad) and "cycle" in p.load_error
+
+
+@pytest.mark.parametrize("W,H", [(75, 32), (96, 96), (20, 20), (31, 57)])
+def test_windows_other_than_24x24(tmp_path, W, H):
+    """The LDS tile geometry follows the cascade's window size (75x32 is the reference's barcode window,
+    traincascade/res/README.md; 96x96 needs more than 64 KiB of LDS per tile)."""
+    xml = cf.lbp_stump_cascade(W, H)
+    n = _check(xml, str(tmp_path), [frame_natural(400, 300, 51), frame_natural(W + 3, H + 40, 52)], sfs=(1.1, 1.5))
+    assert n > 0
