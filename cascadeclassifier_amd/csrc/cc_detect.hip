@@ -466,6 +466,7 @@ struct EvalArgs {
   const int* tree_leaf0;  // first leaf value of each weak classifier
   const float* leaves;
   int wave_below;       // switch to one wavefront per window when fewer windows than this are queued (0 = never)
+  int early_skip;       // drop windows the scan loop provably never visits right after stage 0
   int split_stumps;     // stage sums are exact (order-independent): wavefronts may split a stage's stumps
   int stop_after;       // timing experiments only: drop every window still alive after this stage (-1 = off)
   unsigned long long* masks;
@@ -704,11 +705,30 @@ __device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const
       const int ly = wave * WIN_PER_THREAD + k;
       const int gy = gy0 + ly;
       const int id = ly * 64 + lane;
-      const bool pass = alive[k] && !(acc[k] < thr);
+      bool pass = alive[k] && !(acc[k] < thr);
       const bool rej0 = alive[k] && !pass;
       const unsigned long long m = __ballot(rej0);
       if (lane == 0 && gy < S.ny) A.masks[(size_t)frame * A.mask_frame_words + S.mask_ofs + (size_t)gy * S.nxw + T.y] = m;
       if (dbg && rej0) report(id, 0, acc[k]);
+      // Stage-0 skip rule, applied early: the scan loop never visits a window whose run of consecutive stage-0
+      // rejections immediately to its left has odd length (k_filter_candidates), so such a window can stop here instead
+      // of walking the later stages for nothing. The run is read off the row's ballot mask; when it reaches the left edge
+      // of this tile its length is only known for the first tile of a row, otherwise the window is kept (the final
+      // filter decides). The parity instrumentation evaluates every window, so it is skipped there.
+      if (!dbg && A.early_skip) {
+        const unsigned long long lower = (1ull << lane) - 1ull;
+        const unsigned long long zeros_below = ~m & lower;  // lower lanes that were NOT rejected at stage 0
+        int run;
+        bool known;
+        if (zeros_below) {
+          run = lane - 1 - (63 - __clzll((long long)zeros_below));
+          known = true;
+        } else {
+          run = lane;
+          known = T.y == 0;
+        }
+        if (known && (run & 1)) pass = false;
+      }
       if (A.nstages == 1) {
         if (pass) {
           emit_candidate(id);
@@ -1627,6 +1647,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.wave_below = d->wave_below;
     A.stop_after = d->stop_after;
     A.split_stumps = d->split_stumps;
+    A.early_skip = std::getenv("CCAMD_NO_EARLY_SKIP") ? 0 : 1;
     A.stage_thr = d->d_stage_thr.p;
     A.masks = d->d_masks.p;
     A.mask_frame_words = P->mask_frame_words;
