@@ -22,3 +22,24 @@ def test_cpp_feature_tests_pass_on_the_device(haar_xml):
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0
     assert "0 failed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_detection_tool_matches_python_path(haar_xml, tmp_path):
+    """examples/detect_pgm.cpp (the reference's tools/detection/Cpp/main.cpp minus the GUI) prints the same rectangles as
+    the Python front end for the same frame."""
+    import numpy as np
+
+    import cascadeclassifier_amd as cc
+    from tools.make_golden import golden_frame
+    img = golden_frame()
+    pgm = os.path.join(str(tmp_path), "frame.pgm")
+    with open(pgm, "wb") as f:
+        f.write(b"P5\n# golden frame\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(img.tobytes())
+    want = cc.CascadeClassifier(haar_xml).detectMultiScale(img, 1.1, 3)
+    r = subprocess.run([os.path.join(LIB, "detect_pgm"), haar_xml, pgm, "1.1", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.array([[int(v) for v in line.split()] for line in r.stdout.strip().splitlines()], np.int32).reshape(-1, 4)
+    assert got.shape == want.shape and (got == want).all() and len(got) >= 3
+    assert subprocess.run([os.path.join(LIB, "detect_pgm"), "/nonexistent.xml", pgm], capture_output=True).returncode == 1
