@@ -79,6 +79,7 @@ SIGNATURES = {
     "cc_cascade_stumps": (_i, [_vp, _pp, _pp, _pp, _pp, _pp]),
     "cc_cascade_features": (_i, [_vp, _pp, _pp, _pp]),
     "cc_cascade_save_xml": (_i, [_vp, C.c_char_p]),
+    "cc_cascade_save_xml_legacy": (_i, [_vp, C.c_char_p]),
     "cc_vec_read": (_i, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _vp, _i]),
     "cc_vec_write": (_i, [C.c_char_p, _vp, _i, _i, _i]),
     "cc_detector_create": (_i, [_vp, _i, _i, _pp]),

@@ -276,6 +276,28 @@ std::string real_text(float v) {
     snprintf(b, sizeof(b), "%.8e", (double)v);
   return b;
 }
+// doubles (node values in the legacy layout) go out with "%.16e"
+std::string real_text_d(double v) {
+  char b[64];
+  if (v == (double)(long long)v && v > -1e9 && v < 1e9)
+    snprintf(b, sizeof(b), "%lld.", (long long)v);
+  else
+    snprintf(b, sizeof(b), "%.16e", v);
+  return b;
+}
+// the raw <stageThreshold> whose (float)t - 1e-5f is the stored value; false if no float maps onto it
+bool stage_threshold_preimage(float stored, float& t) {
+  t = stored + 1e-5f;
+  for (int k = 0; k < 64 && (float)(t - 1e-5f) != stored; k++) t = (float)(t - 1e-5f) < stored ? std::nextafterf(t, INFINITY) : std::nextafterf(t, -INFINITY);
+  return (float)(t - 1e-5f) == stored;
+}
+cc_status write_text_file(const char* path, const std::string& text) {
+  std::ofstream f(path, std::ios::binary);
+  if (!f) return set_error(CC_ERR_IO, "cannot open '%s' for writing", path);
+  f.write(text.data(), (std::streamsize)text.size());
+  if (!f) return set_error(CC_ERR_IO, "write to '%s' failed", path);
+  return CC_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -325,10 +347,9 @@ cc_status cc_cascade_save_xml(const cc_cascade* c, const char* path) {
   for (size_t s = 0; s < m.stage_ntrees.size(); s++) {
     // the model keeps (float)stageThreshold - 1e-5f; write back a value that parses to the same float after the
     // reader subtracts the epsilon again: search the neighbourhood of thr + 1e-5f
-    const float stored = m.stage_threshold[s];
-    float t = stored + 1e-5f;
-    for (int k = 0; k < 64 && (float)(t - 1e-5f) != stored; k++) t = (float)(t - 1e-5f) < stored ? std::nextafterf(t, INFINITY) : std::nextafterf(t, -INFINITY);
-    if ((float)(t - 1e-5f) != stored) return set_error(CC_ERR_UNSUPPORTED, "cc_cascade_save_xml: stage threshold %zu has no float pre-image", s);
+    float t;
+    if (!stage_threshold_preimage(m.stage_threshold[s], t))
+      return set_error(CC_ERR_UNSUPPORTED, "cc_cascade_save_xml: stage threshold %zu has no float pre-image", s);
     o << "    <_>\n      <maxWeakCount>" << m.stage_ntrees[s] << "</maxWeakCount>\n      <stageThreshold>" << real_text(t)
       << "</stageThreshold>\n      <weakClassifiers>\n";
     for (int i = 0; i < m.stage_ntrees[s]; i++) {
@@ -366,12 +387,61 @@ cc_status cc_cascade_save_xml(const cc_cascade* c, const char* path) {
     }
   }
   o << "  </features>\n</cascade>\n</opencv_storage>\n";
-  std::ofstream f(path, std::ios::binary);
-  if (!f) return set_error(CC_ERR_IO, "cannot open '%s' for writing", path);
-  const std::string text = o.str();
-  f.write(text.data(), (std::streamsize)text.size());
-  if (!f) return set_error(CC_ERR_IO, "write to '%s' failed", path);
-  return CC_OK;
+  return write_text_file(path, o.str());
+}
+
+cc_status cc_cascade_save_xml_legacy(const cc_cascade* c, const char* path) {
+  if (!c || !path) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_save_xml_legacy: null argument");
+  const Cascade& m = c->m;
+  if (m.feature_type != CC_FEATURE_HAAR)
+    return set_error(CC_ERR_UNSUPPORTED, "old file format is used for Haar-like features only");
+  std::ostringstream o;
+  o << "<?xml version=\"1.0\"?>\n<opencv_storage>\n<cascade type_id=\"opencv-haar-classifier\">\n";
+  o << "  <size>\n    " << m.win_w << " " << m.win_h << "</size>\n  <stages>\n";
+  for (size_t s = 0; s < m.stage_ntrees.size(); s++) {
+    float thr;
+    if (!stage_threshold_preimage(m.stage_threshold[s], thr))
+      return set_error(CC_ERR_UNSUPPORTED, "cc_cascade_save_xml_legacy: stage threshold %zu has no float pre-image", s);
+    o << "    <_>\n      <trees>\n";
+    for (int i = 0; i < m.stage_ntrees[s]; i++) {
+      const size_t t_i = (size_t)m.stage_first[s] + i;
+      const int n0 = m.tree_first_node[t_i], l0 = m.tree_first_leaf[t_i];
+      o << "        <_>\n";
+      // breadth-first walk from the root; an inner child gets the next free number when it is queued
+      std::vector<int> queue(1, 0);
+      int next_idx = 0;
+      for (size_t q = 0; q < queue.size(); q++) {
+        const int k = n0 + queue[q];
+        const int f = m.node_feature[k];
+        o << "          <_>\n            <feature>\n              <rects>\n";
+        for (int j = 0; j < 3; j++) {
+          const int32_t* r = &m.haar_rects[(size_t)f * 12 + j * 4];
+          const float w = m.haar_weights[(size_t)f * 3 + j];
+          if (j > 0 && r[2] == 0 && w == 0.0f) break;
+          o << "                <_>\n                  " << r[0] << " " << r[1] << " " << r[2] << " " << r[3] << " " << real_text(w) << "</_>\n";
+        }
+        o << "              </rects>\n              <tilted>" << (m.haar_tilted[f] ? 1 : 0) << "</tilted></feature>\n";
+        o << "            <threshold>" << real_text(m.node_threshold[k]) << "</threshold>\n";
+        const int child[2] = {m.node_left[k], m.node_right[k]};
+        const char* node_tag[2] = {"left_node", "right_node"};
+        const char* val_tag[2] = {"left_val", "right_val"};
+        for (int side = 0; side < 2; side++) {
+          if (child[side] > 0) {
+            queue.push_back(child[side]);
+            o << "            <" << node_tag[side] << ">" << ++next_idx << "</" << node_tag[side] << ">";
+          } else {
+            o << "            <" << val_tag[side] << ">" << real_text_d((double)m.leaves[l0 - child[side]]) << "</" << val_tag[side] << ">";
+          }
+          o << (side == 0 ? "\n" : "</_>\n");
+        }
+      }
+      o << "        </_>\n";
+    }
+    o << "      </trees>\n      <stage_threshold>" << real_text(thr) << "</stage_threshold>\n      <parent>" << (int)s - 1
+      << "</parent>\n      <next>-1</next></_>\n";
+  }
+  o << "  </stages>\n</cascade>\n</opencv_storage>\n";
+  return write_text_file(path, o.str());
 }
 
 cc_status cc_vec_read(const char* path, int32_t* count, int32_t* vec_size, uint8_t* pixels, int cap_samples) {

@@ -114,9 +114,11 @@ class CascadeClassifier:
     def empty(self) -> bool:
         return not self._c
 
-    def save(self, filename: str):
-        """Write the model back as a new-format cascade.xml (CvCascadeClassifier::save layout)."""
-        L.check(L.lib().cc_cascade_save_xml(self._c, filename.encode()))
+    def save(self, filename: str, baseFormat: bool = False):
+        """Write the model back as a cascade.xml: the new-format layout of CvCascadeClassifier::save, or with
+        baseFormat=True its legacy "opencv-haar-classifier" layout (cascadeclassifier.cpp:439-531; Haar only)."""
+        fn = L.lib().cc_cascade_save_xml_legacy if baseFormat else L.lib().cc_cascade_save_xml
+        L.check(fn(self._c, filename.encode()))
 
     def info(self) -> dict:
         ci = L.CascadeInfo()

@@ -95,6 +95,14 @@ CC_API cc_status cc_cascade_features(const cc_cascade* c, const int32_t** rects,
  * features haarfeatures.cpp:311-320 / lbpfeatures.cpp:65-68). Reading the written file yields an identical model. */
 CC_API cc_status cc_cascade_save_xml(const cc_cascade* c, const char* path);
 
+/* The legacy "baseFormat" layout of CvCascadeClassifier::save(filename, true) (cascadeclassifier.cpp:421-437 tag names,
+ * :457-531 writer): <cascade type_id="opencv-haar-classifier"> with <size>, per stage <trees> (nodes breadth-first from
+ * the root, inner children numbered as they are queued; <feature> = Feature::write, haarfeatures.cpp:311-320; <threshold>,
+ * <left_val>/<left_node>, <right_val>/<right_node>), <stage_threshold>, <parent> = stage - 1, <next> = -1.
+ * Haar cascades only: anything else returns CC_ERR_UNSUPPORTED with the reference's message (:461-462). Write-only, as
+ * in the reference; cc_cascade_load_xml refuses this layout. */
+CC_API cc_status cc_cascade_save_xml_legacy(const cc_cascade* c, const char* path);
+
 /* .vec sample files (positives of the trainer): header int32 count, int32 width*height, 2 x int16 0; per sample one zero
  * byte + width*height int16 pixels. Reader: CvCascadeImageReader::PosReader (traincascade/lib/src/imagestorage.cpp:138-182);
  * writer: icvWriteVecHeader / icvWriteVecSample (tools/createsamples/utility.cpp:128-152). Host-side file IO.

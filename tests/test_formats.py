@@ -78,3 +78,87 @@ def test_vec_errors(tmp_path):
     open(bad, "wb").write(bytes([5, 0, 0, 0, 16, 0, 0, 0, 0, 0, 0, 0, 0]) + b"abc")  # header promises 5 samples of 16 px
     with pytest.raises(cc.CascadeError):
         det.vec_read(bad)
+
+
+def _legacy_walk(tree_el):
+    """(feature geometry, threshold, left, right) per node of one legacy <trees>/<_> element; children are
+    ('node', k) or ('val', v)."""
+    nodes = []
+    for n in [e for e in tree_el if e.tag == "_"]:
+        feat = n.find("feature")
+        rects = [[float(v) for v in r.text.split()] for r in feat.find("rects") if r.tag == "_"]
+        side = []
+        for name in ("left", "right"):
+            if n.find(name + "_node") is not None:
+                side.append(("node", int(n.findtext(name + "_node"))))
+            else:
+                side.append(("val", float(n.findtext(name + "_val"))))
+        nodes.append((rects, int(feat.findtext("tilted")), np.float32(float(n.findtext("threshold"))), side[0], side[1]))
+    return nodes
+
+
+@pytest.mark.parametrize("which", ["haar", "haar_trees"])
+def test_legacy_base_format_writer(tmp_path, haar_xml, which):
+    """cc_cascade_save_xml_legacy writes the layout of CvCascadeClassifier::save(filename, baseFormat=true)
+    (cascadeclassifier.cpp:457-531): every stage, tree, node, feature and value of the model is found again by an
+    independent ElementTree walk, with the breadth-first node numbering of the reference's queue."""
+    import xml.etree.ElementTree as ET
+
+    from oracle import oracle as orc
+    src = cc.CascadeClassifier()
+    if which == "haar":
+        assert src.load(haar_xml)
+        new_xml = haar_xml
+    else:
+        new_xml = os.path.join(str(tmp_path), "trees.xml")
+        open(new_xml, "w").write(cf.haar_tree_cascade(_calib(), with_tilted=True))
+        assert src.load(new_xml)
+    out = os.path.join(str(tmp_path), "legacy.xml")
+    src.save(out, baseFormat=True)
+    root = ET.parse(out).getroot()
+    casc = list(root)[0]
+    assert casc.tag == "cascade" and casc.attrib["type_id"] == "opencv-haar-classifier"
+    assert [int(v) for v in casc.findtext("size").split()] == [src.info()["win_w"], src.info()["win_h"]]
+    o = orc.load_cascade_xml(new_xml)
+    raw_thr = [np.float32(float(s.findtext("stageThreshold"))) for s in ET.parse(new_xml).getroot().iter("_") if s.find("stageThreshold") is not None]
+    stages = [s for s in casc.find("stages") if s.tag == "_"]
+    assert len(stages) == o.nstages
+    tree = 0
+    node0 = 0
+    leaf0 = 0
+    for si, st in enumerate(stages):
+        assert np.float32(float(st.findtext("stage_threshold"))) == raw_thr[si]
+        assert int(st.findtext("parent")) == si - 1 and int(st.findtext("next")) == -1
+        trees = [t for t in st.find("trees") if t.tag == "_"]
+        assert len(trees) == o.stage_ntrees[si]
+        for t in trees:
+            nodes = _legacy_walk(t)
+            nn = int(o.tree_nnodes[tree])
+            assert len(nodes) == nn
+            # walk both representations from the root in the writer's breadth-first order
+            order = [0]
+            next_idx = 0
+            for q, (rects, tilted, thr, left, right) in enumerate(nodes):
+                k = node0 + order[q]
+                f = int(o.node_feature[k])
+                want = [[*o.haar["r"][f, j], o.haar["wt"][f, j]] for j in range(3) if j == 0 or o.haar["r"][f, j, 2] != 0 or o.haar["wt"][f, j] != 0]
+                assert rects == [[float(v) for v in r] for r in want] and tilted == int(o.haar["tilted"][f])
+                assert thr == o.node_threshold[k]
+                for (kind, v), child in ((left, int(o.node_left[k])), (right, int(o.node_right[k]))):
+                    if child > 0:
+                        next_idx += 1
+                        order.append(child)
+                        assert (kind, v) == ("node", next_idx)
+                    else:
+                        assert kind == "val" and np.float32(v) == o.leaves[leaf0 - child]
+            tree += 1
+            node0 += nn
+            leaf0 += nn + 1
+    assert tree == len(o.tree_nnodes)
+    # the product's reader refuses the legacy layout (as documented), and LBP cascades cannot be written in it
+    assert not cc.CascadeClassifier().load(out)
+
+
+def test_legacy_base_format_is_haar_only(tmp_path, lbp_xml):
+    with pytest.raises(cc.CascadeError, match="old file format is used for Haar-like features only"):
+        cc.CascadeClassifier(lbp_xml).save(os.path.join(str(tmp_path), "x.xml"), baseFormat=True)
