@@ -60,6 +60,11 @@ class DetectorTimings(C.Structure):
                 ("integral_elems", C.c_int64)]
 
 
+class Split(C.Structure):
+    _fields_ = [("found", C.c_int32), ("var_idx", C.c_int32), ("quality", C.c_float), ("ord_c", C.c_float),
+                ("split_point", C.c_int32), ("subset", C.c_int32 * 8)]
+
+
 class HaarFeatureC(C.Structure):
     _fields_ = [("tilted", C.c_int32), ("r", (C.c_int32 * 4) * 3), ("w", C.c_float * 3)]
 
@@ -115,6 +120,9 @@ SIGNATURES = {
     "cc_eval_get_sample": (_i, [_vp, _i, _vp, _vp, _vp]),
     "cc_eval_predict_cascade": (_i, [_vp, _vp, _vp, _i, _vp]),
     "cc_eval_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double)]),
+    "cc_eval_presort": (_i, [_vp, _i]),
+    "cc_eval_presort_range": (_i, [_vp, _i, _i, _i]),
+    "cc_eval_find_best_split": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _d, _i, _i, C.POINTER(Split), _vp, _vp]),
     "cc_negminer_create": (_i, [_vp, _i, _pp]),
     "cc_negminer_destroy": (None, [_vp]),
     "cc_negminer_plan": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(_i), C.POINTER(C.c_int64)]),

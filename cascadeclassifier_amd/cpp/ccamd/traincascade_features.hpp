@@ -78,6 +78,12 @@ class CvFeatureEvaluator {  // traincascade_features.h:155-188
   // values (optional) + per-feature argsort of samples 0..nSamples-1: the rows precalculate() stores in `buf`
   // (unsigned short when sample_count < 65536, else int; o_cvcascadeboosttraindata.cpp:250-251,490-556)
   void calcBatchSorted(int fiBegin, int fiEnd, int nSamples, float* vals, void* sortedIdx, bool idx16) const;
+  // Node split search on the device (CvDTree::find_best_split, o_cvdtree.cpp:345-357): presort() once per stage after
+  // the samples are set, then findBestSplit() per tree node with the node's sample slots, CvBoostTree::calc_node_value's
+  // subtree weights (n + 2 doubles) and either the ordered responses (LOGIT / GENTLE) or the 0/1 class labels.
+  void presort(int nSamples) const;
+  cc_split findBestSplit(const int* sampleIdx, int n, const double* subtreeWeights, const float* ordResponses,
+                         const int* classLabels, double nodeValue, int boostType, int splitCriteria) const;
   cc_evaluator* handle() const { return h; }
 
  protected:

@@ -226,6 +226,17 @@ void CvFeatureEvaluator::calcBatch(int fiBegin, int fiEnd, const int* sampleIdx,
   check(cc_eval_calc_batch(h, fiBegin, fiEnd, sampleIdx, nSamples, out, 0), "CvFeatureEvaluator::calcBatch");
 }
 
+void CvFeatureEvaluator::presort(int nSamples) const { check(cc_eval_presort(h, nSamples), "CvFeatureEvaluator::presort"); }
+
+cc_split CvFeatureEvaluator::findBestSplit(const int* sampleIdx, int n, const double* subtreeWeights, const float* ordResponses,
+                                           const int* classLabels, double nodeValue, int boostType, int splitCriteria) const {
+  cc_split sp;
+  check(cc_eval_find_best_split(h, sampleIdx, n, subtreeWeights, ordResponses, classLabels, nodeValue, boostType, splitCriteria, &sp,
+                                nullptr, nullptr),
+        "CvFeatureEvaluator::findBestSplit");
+  return sp;
+}
+
 void CvFeatureEvaluator::calcBatchSorted(int fiBegin, int fiEnd, int nSamples, float* vals, void* sortedIdx, bool idx16) const {
   check(cc_eval_calc_batch_sorted(h, fiBegin, fiEnd, nSamples, vals, sortedIdx, idx16 ? 2 : 4), "CvFeatureEvaluator::calcBatchSorted");
 }

@@ -16,26 +16,9 @@
 #include <memory>
 #include <mutex>
 
-#include "cc_internal.h"
+#include "cc_eval_internal.h"
 
 namespace ccamd {
-
-#define CC_HIP(expr)                                                                                         \
-  do {                                                                                                       \
-    hipError_t e_ = (expr);                                                                                  \
-    if (e_ != hipSuccess) return set_error(CC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                                           __FILE__, __LINE__);                                              \
-  } while (0)
-
-// Haar feature with the reference's fastRect offsets (row stride W+1) — haarfeatures.cpp:266-309.
-struct HaarFeatDev {
-  int p[3][4];
-  float w[3];
-  int tilted;
-};
-struct LbpFeatDev {
-  int p[16];
-};
 
 // ------------------------------------------------------------------------------------------------
 // setImage for a batch: one 64-thread block per sample.
@@ -290,24 +273,6 @@ __global__ void k_feature_calc_rows(const HaarFeatDev* __restrict__ feats, int n
   out[i] = ret;
 }
 
-template <class T>
-struct EBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  ~EBuf() {
-    if (p) (void)hipFree(p);
-  }
-  hipError_t ensure(size_t count) {
-    if (count <= n) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
-    if (e == hipSuccess) n = count;
-    return e;
-  }
-};
-
 // `mul` scales the offsets (the batch kernel's LDS tile is [entry][S samples]: entry offsets are pre-multiplied by S).
 static void haar_to_dev(const HaarFeature& f, int step, HaarFeatDev& d, int mul = 1) {
   std::memset(&d, 0, sizeof(d));
@@ -340,38 +305,9 @@ static void lbp_to_dev(const int32_t* r, int step, LbpFeatDev& d, int mul = 1) {
 
 using namespace ccamd;
 
-struct cc_evaluator {
-  int type = 0, mode = 0, W = 0, H = 0, max_samples = 0, device = 0, cols = 0;
-  bool use_tilted = false;
-  std::vector<HaarFeature> haar;
-  std::vector<int32_t> lbp;
-  std::vector<float> cls;
-  int nfeat = 0;
-  hipStream_t stream = nullptr;
-  EBuf<int32_t> d_sum, d_tilted;
-  EBuf<float> d_nf;
-  EBuf<HaarFeatDev> d_haar;
-  EBuf<LbpFeatDev> d_lbp;
-  // scratch (guarded by mu: the calc entry points may be called concurrently)
-  std::mutex mu;
-  EBuf<uint8_t> d_imgs;
-  EBuf<int32_t> d_idx;
-  EBuf<float> d_out;
-  EBuf<HaarFeatDev> d_custom;
-  EBuf<uint8_t> d_pred;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr;
-  double last_ms = 0;
-  int S = 16;
-  ~cc_evaluator() {
-    if (ev_a) (void)hipEventDestroy(ev_a);
-    if (ev_b) (void)hipEventDestroy(ev_b);
-    if (stream) (void)hipStreamDestroy(stream);
-  }
-};
-
 namespace ccamd {
 
-static cc_status eval_device(cc_evaluator* e) {
+cc_status eval_device(cc_evaluator* e) {
   int n = 0;
   hipError_t err = hipGetDeviceCount(&n);
   if (err != hipSuccess || n <= 0)
@@ -382,9 +318,8 @@ static cc_status eval_device(cc_evaluator* e) {
   return CC_OK;
 }
 
-// Launches k_eval_batch over `feats` [fb, fe) for ns samples into d_out_ptr (device). Caller holds e->mu.
-static cc_status launch_batch(cc_evaluator* e, bool haar, const void* feats, int fb, int fe, const int32_t* d_idx, int ns,
-                              float* d_out_ptr, int normalized) {
+cc_status launch_batch(cc_evaluator* e, bool haar, const void* feats, int fb, int fe, const int32_t* d_idx, int ns,
+                       float* d_out_ptr, int normalized) {
   BatchArgs A;
   A.sum = e->d_sum.p;
   A.tilted = e->use_tilted ? e->d_tilted.p : nullptr;

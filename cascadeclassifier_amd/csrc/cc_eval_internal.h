@@ -1,0 +1,117 @@
+// Shared between cc_eval.hip (evaluator, bulk operator(), predict) and cc_split.hip (best-split search): device-side
+// feature records, the evaluator handle and the helpers both translation units use.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
+#include "cc_internal.h"
+
+namespace ccamd {
+
+#define CC_HIP(expr)                                                                                         \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) return set_error(CC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                           __FILE__, __LINE__);                                              \
+  } while (0)
+
+// Haar feature with the reference's fastRect offsets (row stride W+1) — haarfeatures.cpp:266-309.
+struct HaarFeatDev {
+  int p[3][4];
+  float w[3];
+  int tilted;
+};
+struct LbpFeatDev {
+  int p[16];
+};
+
+template <class T>
+struct EBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~EBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t ensure(size_t count) {
+    if (count <= n) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+};
+
+
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~PinnedBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  hipError_t ensure(size_t b) {
+    if (b <= bytes) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipHostMalloc(&p, b, hipHostMallocDefault);
+    if (e == hipSuccess) bytes = b;
+    return e;
+  }
+};
+
+cc_status eval_device(cc_evaluator* e);
+// Launches k_eval_batch over `feats` [fb, fe) for ns samples into d_out_ptr (device). Caller holds e->mu.
+cc_status launch_batch(cc_evaluator* e, bool haar, const void* feats, int fb, int fe, const int32_t* d_idx, int ns,
+                       float* d_out_ptr, int normalized);
+
+}  // namespace ccamd
+
+struct cc_evaluator {
+  using HaarFeature = ccamd::HaarFeature;
+  template <class T>
+  using EBuf = ccamd::EBuf<T>;
+  using HaarFeatDev = ccamd::HaarFeatDev;
+  using LbpFeatDev = ccamd::LbpFeatDev;
+  int type = 0, mode = 0, W = 0, H = 0, max_samples = 0, device = 0, cols = 0;
+  bool use_tilted = false;
+  std::vector<HaarFeature> haar;
+  std::vector<int32_t> lbp;
+  std::vector<float> cls;
+  int nfeat = 0;
+  hipStream_t stream = nullptr;
+  EBuf<int32_t> d_sum, d_tilted;
+  EBuf<float> d_nf;
+  EBuf<HaarFeatDev> d_haar;
+  EBuf<LbpFeatDev> d_lbp;
+  // scratch (guarded by mu: the calc entry points may be called concurrently)
+  std::mutex mu;
+  EBuf<uint8_t> d_imgs;
+  EBuf<int32_t> d_idx;
+  EBuf<float> d_out;
+  EBuf<HaarFeatDev> d_custom;
+  EBuf<uint8_t> d_pred;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  double last_ms = 0;
+  int S = 16;
+  // resident tables of the split search (cc_eval_presort): per group of 64 features the sorted values and sample
+  // indices, interleaved so that lane = feature reads are coalesced: [group][rank][64]
+  EBuf<float> d_sorted_val;
+  EBuf<uint16_t> d_sorted_idx16;
+  EBuf<int32_t> d_sorted_idx32;
+  EBuf<uint8_t> d_codes;  // LBP: [feature][sample] codes
+  int presort_n = 0;      // samples covered by the tables (0 = none)
+  int presort_f0 = 0, presort_f1 = 0;  // variables covered by the tables
+  EBuf<double> d_split_tab, d_split_out;
+  EBuf<int32_t> d_split_idx;
+  ccamd::PinnedBuf pin_in, pin_out;
+  ~cc_evaluator() {
+    if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_b) (void)hipEventDestroy(ev_b);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+

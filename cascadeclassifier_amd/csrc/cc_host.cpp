@@ -2,6 +2,7 @@
 // pyramid geometry, the tap tables of the fixed-point bilinear resize, rectangle grouping and the feature catalogs.
 // Everything that scales with pixels / windows / samples runs in the HIP kernels (cc_detect.hip, cc_eval.hip).
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -238,6 +239,103 @@ void lbp_catalog(int W, int H, std::vector<int32_t>& rects) {
             rects.push_back(w);
             rects.push_back(h);
           }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Categorical split: category ordering + scan (o_cvboostree.cpp:289-357 classification, :466-515 regression).
+// The accumulation over samples happened on the device; this is the O(n_cat log n_cat) remainder. std::sort with a
+// plain `<` on the keys is the reference's call (LessThanPtr over pointers compares the same doubles), so categories
+// with equal keys come out in the same order as there.
+// ------------------------------------------------------------------------------------------------
+void split_categories(const double* hist, int n_cat, bool is_classifier, bool gini, CatSplit& out) {
+  const double feps = (double)FLT_EPSILON;
+  out.found = false;
+  out.quality = -1;
+  out.n_left = 0;
+  std::memset(out.subset, 0, sizeof(out.subset));
+  std::vector<int> order((size_t)n_cat);
+  std::vector<double> key((size_t)n_cat);
+  for (int c = 0; c < n_cat; c++) order[(size_t)c] = c;
+  double best = -1.0;  // init_quality of a search on its own
+  int best_pos = -1;
+  if (!is_classifier) {
+    std::vector<double> tot((size_t)n_cat), cnt((size_t)n_cat);
+    double right_w = 0, right_s = 0;
+    for (int c = 0; c < n_cat; c++) {
+      const double s = hist[2 * c], w = hist[2 * c + 1];
+      right_w += w;
+      right_s += s;
+      cnt[(size_t)c] = w;
+      key[(size_t)c] = std::fabs(w) > DBL_EPSILON ? s / w : 0;  // average response of the category
+    }
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return key[(size_t)a] < key[(size_t)b]; });
+    for (int c = 0; c < n_cat; c++) tot[(size_t)c] = key[(size_t)c] * cnt[(size_t)c];  // "revert back to unnormalized sums"
+    double left_w = 0, left_s = 0;
+    for (int pos = 0; pos < n_cat - 1; pos++) {
+      const int c = order[(size_t)pos];
+      const double w = cnt[(size_t)c];
+      if (!(w > feps)) continue;
+      const double s = tot[(size_t)c];
+      left_s += s;
+      left_w += w;
+      right_s -= s;
+      right_w -= w;
+      if (left_w > feps && right_w > feps) {
+        const double val = (left_s * left_s * right_w + right_s * right_s * left_w) / (left_w * right_w);
+        if (best < val) {
+          best = val;
+          best_pos = pos;
+        }
+      }
+    }
+  } else {
+    double lcw[2] = {0, 0}, rcw[2] = {0, 0};
+    for (int c = 0; c < n_cat; c++) {
+      rcw[0] += hist[2 * c];
+      rcw[1] += hist[2 * c + 1];
+      key[(size_t)c] = hist[2 * c + 1];  // weight of the category's class-1 samples
+    }
+    double left_w = 0, right_w = rcw[0] + rcw[1];
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return key[(size_t)a] < key[(size_t)b]; });
+    for (int pos = 0; pos < n_cat - 1; pos++) {
+      const int c = order[(size_t)pos];
+      const double w0 = hist[2 * c], w1 = hist[2 * c + 1];
+      const double weight = w0 + w1;
+      if (weight < feps) continue;
+      lcw[0] += w0;
+      rcw[0] -= w0;
+      lcw[1] += w1;
+      rcw[1] -= w1;
+      if (gini) {
+        const double lsum2 = lcw[0] * lcw[0] + lcw[1] * lcw[1];
+        const double rsum2 = rcw[0] * rcw[0] + rcw[1] * rcw[1];
+        left_w += weight;
+        right_w -= weight;
+        if (left_w > feps && right_w > feps) {
+          const double val = (lsum2 * right_w + rsum2 * left_w) / (left_w * right_w);
+          if (best < val) {
+            best = val;
+            best_pos = pos;
+          }
+        }
+      } else {
+        const double a = lcw[0] + rcw[1], b = lcw[1] + rcw[0];
+        const double val = a > b ? a : b;
+        if (best < val) {
+          best = val;
+          best_pos = pos;
+        }
+      }
+    }
+  }
+  if (best_pos < 0) return;
+  out.found = true;
+  out.quality = best;
+  out.n_left = best_pos + 1;
+  for (int pos = 0; pos <= best_pos; pos++) {
+    const int c = order[(size_t)pos];
+    out.subset[c >> 5] |= 1 << (c & 31);
+  }
 }
 
 }  // namespace ccamd

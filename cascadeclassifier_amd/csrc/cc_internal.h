@@ -84,6 +84,18 @@ void group_rectangles(std::vector<cc_rect>& rects, int group_threshold, double e
 void haar_catalog(int W, int H, int mode, std::vector<HaarFeature>& out);
 void lbp_catalog(int W, int H, std::vector<int32_t>& rects);
 
+// ---- split search, categorical variables: the part after the per-category accumulation (host) ------
+// hist: n_cat pairs, regression {sum of response*w, sum of w}, classification {w of class 0, w of class 1}, each
+// accumulated in node sample order. Orders the categories and scans them as find_split_cat_reg / find_split_cat_class
+// do (o_cvboostree.cpp:466-515, 289-357) with init_quality -1.
+struct CatSplit {
+  bool found;
+  double quality;      // best_val (double, before the cast to float)
+  int n_left;          // categories sent left
+  int32_t subset[8];
+};
+void split_categories(const double* hist, int n_cat, bool is_classifier, bool gini, CatSplit& out);
+
 }  // namespace ccamd
 
 struct cc_cascade {

@@ -1,0 +1,613 @@
+// Best-split search of a boosted-tree node on gfx950 (section 6 of the C ABI).
+// Replaces CvDTree::find_best_split (traincascade/lib/src/o_cvdtree.cpp:313-357) with the per-variable searches of
+// CvBoostTree (o_cvboostree.cpp:151-516) over the variable data of CvCascadeBoostTrainData
+// (o_cvcascadeboosttraindata.cpp:403-482).
+//
+// MI355X-first shape: the reference keeps a budgeted slice of sorted indices in host memory and re-evaluates + re-sorts
+// every other variable for every node; here the sorted order of EVERY variable stays resident in HBM for the whole
+// stage (6 B per (variable, sample): 19.5 GB for 162 336 x 20 000), and one node search is a single streaming pass.
+//
+// Data layout in HBM (cc_eval_presort): variables in groups of 64; per group the sorted values (f32) and sample indices
+// (u16 when n_samples <= 65 536, else i32) are interleaved [group][rank][64 lanes], so that lane = variable reads of
+// one rank are one coalesced 256-B / 128-B segment. LBP: category codes u8 [variable][sample].
+//
+// The running sums of the reference are sequential double additions in sorted order; they are reproduced bit for bit by
+// giving each variable to one thread. Parallelism comes from the 10^5 variables, not from the scan.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <thread>
+
+#include "cc_eval_internal.h"
+
+namespace ccamd {
+
+// per stored sample: weight and (regression) response * weight or (classification) class; w < 0 marks "not in the node"
+struct SplitEntry {
+  double w, t;
+};
+
+// ------------------------------------------------------------------------------------------------
+// [rows][n] row-major (one sorted variable per row) -> [group][rank][64]
+// ------------------------------------------------------------------------------------------------
+template <class TI>
+__global__ __launch_bounds__(256) void k_interleave(const float* __restrict__ vals, const int* __restrict__ idx, int rows, int n,
+                                                    float* __restrict__ out_val, TI* __restrict__ out_idx, size_t group0) {
+  __shared__ float tv[64][65];
+  __shared__ int ti[64][65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 64, g = blockIdx.y;
+  for (int j = wave; j < 64; j += 4) {
+    const int row = g * 64 + j;
+    float v = 0.f;
+    int s = 0;
+    if (row < rows && r0 + lane < n) {
+      v = vals[(size_t)row * n + r0 + lane];
+      s = idx[(size_t)row * n + r0 + lane];
+    }
+    tv[j][lane] = v;
+    ti[j][lane] = s;
+  }
+  __syncthreads();
+  for (int rr = wave; rr < 64; rr += 4) {
+    if (r0 + rr >= n) break;
+    const size_t o = ((group0 + g) * (size_t)n + r0 + rr) * 64 + lane;
+    out_val[o] = tv[lane][rr];
+    out_idx[o] = (TI)ti[lane][rr];
+  }
+}
+
+__global__ void k_codes_u8(const float* __restrict__ in, uint8_t* __restrict__ out, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) out[i] = (uint8_t)(int)in[i];
+}
+
+__global__ void k_iota_rows2(int* __restrict__ v, size_t total, int n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) v[i] = (int)(i % (size_t)n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ordered variables: one thread per variable walks its sorted samples.
+//   MODE 0: find_split_ord_reg   (o_cvboostree.cpp:361-426)
+//   MODE 1: find_split_ord_class, GINI      (o_cvboostree.cpp:192-221)
+//   MODE 2: find_split_ord_class, MISCLASS  (o_cvboostree.cpp:222-238)
+// The reference tests the boundary between sorted positions i and i+1 after adding sample i; here the test happens when
+// the NEXT node member arrives (samples outside the node are skipped), which is the same sequence of operations.
+// ------------------------------------------------------------------------------------------------
+struct SplitOrdArgs {
+  const float* sv;
+  const void* si;
+  const SplitEntry* tab;
+  int n_pre;       // samples per variable in the tables
+  int n_vars;
+  double w_total0, w_total1;  // weights[n], weights[n + 1]
+  double rsum0;               // node_value * weights[n]
+  double* best_val;
+  int* best_i;
+  float* best_vl;
+  float* best_vr;
+  int n_groups;
+  int dbg_nogather;  // timing experiment (CCAMD_DEBUG_SPLIT_NOGATHER): every lane reads table entry `lane`
+};
+
+// TAB selects where the per-sample table lives: 0 = global memory (16-B entries; any size), 1 = LDS, 16-B entries,
+// 2 = LDS, 8-B entries (regression with responses +-1: entry = response * w, w = |entry|; classification: entry = w with
+// the class in the sign bit; NaN = not in the node). A wavefront's 64 lanes gather 64 unrelated entries per rank, which
+// costs ~64 L2 requests from global memory but a few LDS cycles from a block-resident copy.
+template <int MODE, class TI, int TAB>
+__global__ __launch_bounds__(1024) void k_split_ord(SplitOrdArgs A) {
+  extern __shared__ double l_tab[];
+  const int lane = threadIdx.x & 63;
+  const int group = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (TAB != 0) {
+    const int words = A.n_pre * (TAB == 1 ? 2 : 1);
+    const double* src = reinterpret_cast<const double*>(A.tab);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) l_tab[i] = src[i];
+    __syncthreads();
+  }
+  if (group >= A.n_groups) return;
+  const int f = group * 64 + lane;
+  const size_t base = (size_t)group * A.n_pre * 64 + lane;
+  const float* sv = A.sv + base;
+  const TI* si = reinterpret_cast<const TI*>(A.si) + base;
+  const float epsilon = FLT_EPSILON * 2;
+  double L = 0, R, lsum = 0, rsum = 0, lcw0 = 0, lcw1 = 0, rcw0 = A.w_total0, rcw1 = A.w_total1;
+  if (MODE == 0) {
+    R = A.w_total0;
+    rsum = A.rsum0;
+  } else {
+    R = rcw0 + rcw1;
+    rsum = rcw0 * rcw0 + rcw1 * rcw1;  // rsum2; lsum plays lsum2
+  }
+  double best_val = -1.0;
+  int best_i = -1, count = 0;
+  float prev = 0.f, vl = 0.f, vr = 0.f;
+  constexpr int U = 8;
+  for (int r0 = 0; r0 < A.n_pre; r0 += U) {
+    float v[U];
+    SplitEntry e[U];
+    unsigned s[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const bool in = r0 + k < A.n_pre;
+      v[k] = in ? sv[(size_t)(r0 + k) * 64] : 0.f;
+      s[k] = in ? (unsigned)si[(size_t)(r0 + k) * 64] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const unsigned g = A.dbg_nogather ? (unsigned)lane : s[k];
+      if (TAB == 0)
+        e[k] = A.tab[g];
+      else if (TAB == 1)
+        e[k] = reinterpret_cast<const SplitEntry*>(l_tab)[g];
+      else {
+        const double x = l_tab[g];
+        e[k].w = fabs(x);  // NaN stays NaN: fails the membership test below
+        e[k].t = MODE == 0 ? x : (__double_as_longlong(x) < 0 ? 1.0 : 0.0);
+      }
+      if (r0 + k >= A.n_pre) e[k].w = -1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const double w = e[k].w;
+      if (!(w >= 0.0)) continue;
+      if (count > 0 && prev + epsilon < v[k]) {
+        double val;
+        bool candidate = true;
+        if (MODE == 2) {
+          const double a = lcw0 + rcw1, b = lcw1 + rcw0;
+          val = a > b ? a : b;
+        } else {
+          const double num = MODE == 0 ? lsum * lsum * R + rsum * rsum * L : lsum * R + rsum * L;
+          const double den = L * R;
+          // The quotient can only matter if it exceeds best_val. num < best_val * den * (1 - 2^-50) (two roundings,
+          // each within 2^-53) implies num / den < best_val exactly, hence fl(num / den) <= best_val: the division
+          // is skipped without changing any result. Anything else (incl. den <= 0, NaN) takes the division.
+          candidate = !(den > 0.0 && num < best_val * den * (1.0 - 0x1p-50));
+          val = candidate ? num / den : 0.0;
+        }
+        if (candidate && best_val < val) {
+          best_val = val;
+          best_i = count - 1;
+          vl = prev;
+          vr = v[k];
+        }
+      }
+      if (MODE == 0) {
+        const double t = e[k].t;
+        L += w;
+        R -= w;
+        lsum += t;
+        rsum -= t;
+      } else {
+        const bool c1 = e[k].t != 0.0;
+        if (MODE == 1) {
+          const double w2 = w * w;
+          L += w;
+          R -= w;
+          const double lv = c1 ? lcw1 : lcw0, rv = c1 ? rcw1 : rcw0;
+          lsum += 2 * lv * w + w2;
+          rsum -= 2 * rv * w - w2;
+          if (c1) {
+            lcw1 = lv + w;
+            rcw1 = rv - w;
+          } else {
+            lcw0 = lv + w;
+            rcw0 = rv - w;
+          }
+        } else {
+          if (c1) {
+            lcw1 += w;
+            rcw1 -= w;
+          } else {
+            lcw0 += w;
+            rcw0 -= w;
+          }
+        }
+      }
+      prev = v[k];
+      count++;
+    }
+  }
+  if (f < A.n_vars) {
+    A.best_val[f] = best_val;
+    A.best_i[f] = best_i;
+    A.best_vl[f] = vl;
+    A.best_vr[f] = vr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Categorical variables (LBP, 256 categories): one block per variable, one thread per category; the node's samples are
+// streamed through LDS in node order and every thread adds the samples of its own category, i.e. each category's sums
+// are accumulated in the reference's order (o_cvboostree.cpp:456-464 regression, :283-288 classification).
+// hist[var][category] = {sum of response*w, sum of w} or {w of class 0, w of class 1}.
+// ------------------------------------------------------------------------------------------------
+template <bool CLASSIFIER>
+__global__ __launch_bounds__(256) void k_split_cat(const uint8_t* __restrict__ codes, int n_pre, const int32_t* __restrict__ node_idx,
+                                                   const SplitEntry* __restrict__ node_tab, int n, double* __restrict__ hist) {
+  __shared__ int l_code[256];
+  __shared__ double l_w[256], l_t[256];
+  const int f = blockIdx.x, cat = threadIdx.x;
+  double a0 = 0, a1 = 0;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    int code = -1;
+    double w = 0, t = 0;
+    if (i < n) {
+      const int g = node_idx ? node_idx[i] : i;
+      code = codes[(size_t)f * n_pre + g];
+      const SplitEntry e = node_tab[i];
+      w = e.w;
+      t = e.t;
+    }
+    l_code[threadIdx.x] = code;
+    l_w[threadIdx.x] = w;
+    l_t[threadIdx.x] = t;
+    __syncthreads();
+    const int m = min(256, n - i0);
+    for (int j = 0; j < m; j++) {
+      if (l_code[j] == cat) {
+        if (CLASSIFIER) {
+          if (l_t[j] != 0.0)
+            a1 += l_w[j];
+          else
+            a0 += l_w[j];
+        } else {
+          a0 += l_t[j];
+          a1 += l_w[j];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  hist[((size_t)f * 256 + cat) * 2] = a0;
+  hist[((size_t)f * 256 + cat) * 2 + 1] = a1;
+}
+
+}  // namespace ccamd
+
+using namespace ccamd;
+
+extern "C" {
+
+cc_status cc_eval_presort_range(cc_evaluator* e, int fi_begin, int fi_end, int n_samples) {
+  if (!e) return set_error(CC_ERR_INVALID_ARG, "cc_eval_presort: null evaluator");
+  if (n_samples < 1 || n_samples > e->max_samples)
+    return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_presort: n_samples %d out of range (max_samples %d)", n_samples, e->max_samples);
+  if (fi_begin < 0 || fi_end > e->nfeat || fi_begin >= fi_end)
+    return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_presort: features [%d, %d) out of range (%d)", fi_begin, fi_end, e->nfeat);
+  cc_status st = eval_device(e);
+  if (st != CC_OK) return st;
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->presort_n = 0;
+  const bool haar = e->type == CC_FEATURE_HAAR;
+  const int F = fi_end - fi_begin, N = n_samples;
+  const void* feats = haar ? (const void*)e->d_haar.p : (const void*)e->d_lbp.p;
+  // variables per pass: whole groups of 64, at most 2^28 values per scratch array
+  int FB = (int)std::min<size_t>((size_t)F, std::max<size_t>(64, (((size_t)1 << 28) / (size_t)N) / 64 * 64));
+  const size_t groups = ((size_t)F + 63) / 64;
+  size_t free_b = 0, total_b = 0;
+  CC_HIP(hipMemGetInfo(&free_b, &total_b));
+  const size_t resident = haar ? groups * 64 * (size_t)N * (4 + (N <= 65536 ? 2 : 4)) : (size_t)F * N;
+  const size_t have = e->d_sorted_val.n * 4 + e->d_sorted_idx16.n * 2 + e->d_sorted_idx32.n * 4 + e->d_codes.n + e->d_out.n * 4;
+  const size_t scratch = (size_t)FB * N * (haar ? 16 : 4);
+  if (resident + scratch > free_b + have)
+    return set_error(CC_ERR_UNSUPPORTED, "cc_eval_presort: needs %.1f GB of device memory (%.1f GB free)",
+                     (double)(resident + scratch) / 1e9, (double)(free_b + have) / 1e9);
+  if (!haar) {
+    CC_HIP(e->d_codes.ensure((size_t)F * N));
+    for (int f0 = 0; f0 < F; f0 += FB) {
+      const int f1 = std::min(F, f0 + FB);
+      const size_t total = (size_t)(f1 - f0) * N;
+      CC_HIP(e->d_out.ensure(total));
+      st = launch_batch(e, false, feats, fi_begin + f0, fi_begin + f1, nullptr, N, e->d_out.p, 1);
+      if (st != CC_OK) return st;
+      hipLaunchKernelGGL(k_codes_u8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, e->d_out.p,
+                         e->d_codes.p + (size_t)f0 * N, total);
+    }
+    CC_HIP(hipGetLastError());
+    CC_HIP(hipStreamSynchronize(e->stream));
+    e->presort_n = N;
+    e->presort_f0 = fi_begin;
+    e->presort_f1 = fi_end;
+    return CC_OK;
+  }
+  const bool idx16 = N <= 65536;
+  CC_HIP(e->d_sorted_val.ensure(groups * 64 * (size_t)N));
+  if (idx16)
+    CC_HIP(e->d_sorted_idx16.ensure(groups * 64 * (size_t)N));
+  else
+    CC_HIP(e->d_sorted_idx32.ensure(groups * 64 * (size_t)N));
+  EBuf<float> keys_out;
+  EBuf<int> iota, sorted, offsets;
+  EBuf<char> temp;
+  const size_t cap = (size_t)FB * N;
+  CC_HIP(e->d_out.ensure(cap));
+  CC_HIP(keys_out.ensure(cap));
+  CC_HIP(iota.ensure(cap));
+  CC_HIP(sorted.ensure(cap));
+  CC_HIP(offsets.ensure((size_t)FB + 1));
+  std::vector<int> off((size_t)FB + 1);
+  for (int i = 0; i <= FB; i++) off[(size_t)i] = (int)((size_t)i * N);
+  CC_HIP(hipMemcpyAsync(offsets.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_iota_rows2, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, e->stream, iota.p, cap, N);
+  for (int f0 = 0; f0 < F; f0 += FB) {
+    const int f1 = std::min(F, f0 + FB), nf = f1 - f0;
+    const size_t total = (size_t)nf * N;
+    st = launch_batch(e, true, feats, fi_begin + f0, fi_begin + f1, nullptr, N, e->d_out.p, 1);
+    if (st != CC_OK) return st;
+    size_t temp_bytes = 0;
+    CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
+                                                       offsets.p, offsets.p + 1, 0, 32, e->stream));
+    CC_HIP(temp.ensure(std::max<size_t>(temp_bytes, 1)));
+    // stable: equal values keep increasing sample order
+    CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(temp.p, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
+                                                       offsets.p, offsets.p + 1, 0, 32, e->stream));
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((nf + 63) / 64));
+    if (idx16)
+      hipLaunchKernelGGL((k_interleave<uint16_t>), grid, dim3(256), 0, e->stream, keys_out.p, sorted.p, nf, N, e->d_sorted_val.p,
+                         e->d_sorted_idx16.p, (size_t)f0 / 64);
+    else
+      hipLaunchKernelGGL((k_interleave<int32_t>), grid, dim3(256), 0, e->stream, keys_out.p, sorted.p, nf, N, e->d_sorted_val.p,
+                         e->d_sorted_idx32.p, (size_t)f0 / 64);
+    CC_HIP(hipGetLastError());
+  }
+  CC_HIP(hipStreamSynchronize(e->stream));
+  e->presort_n = N;
+  e->presort_f0 = fi_begin;
+  e->presort_f1 = fi_end;
+  return CC_OK;
+}
+
+cc_status cc_eval_presort(cc_evaluator* e, int n_samples) {
+  if (!e) return set_error(CC_ERR_INVALID_ARG, "cc_eval_presort: null evaluator");
+  return cc_eval_presort_range(e, 0, e->nfeat, n_samples);
+}
+
+cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, int n, const double* weights, const float* responses,
+                                  const int32_t* class_labels, double node_value, int boost_type, int split_criteria, cc_split* out,
+                                  double* per_var_quality, int32_t* per_var_point) {
+  if (!e || !weights || !out) return set_error(CC_ERR_INVALID_ARG, "cc_eval_find_best_split: null argument");
+  if (boost_type < 0 || boost_type > 3) return set_error(CC_ERR_INVALID_ARG, "cc_eval_find_best_split: unknown boost type %d", boost_type);
+  const bool is_classifier = boost_type == 0 || boost_type == 1;
+  if (is_classifier ? !class_labels : !responses)
+    return set_error(CC_ERR_INVALID_ARG, "cc_eval_find_best_split: %s", is_classifier ? "class_labels required for DISCRETE / REAL boost"
+                                                                                        : "responses required for LOGIT / GENTLE boost");
+  if (e->presort_n <= 0) return set_error(CC_ERR_INVALID_ARG, "cc_eval_find_best_split: call cc_eval_presort first");
+  const int N = e->presort_n;
+  if (n < 0 || n > N) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_find_best_split: n %d exceeds the %d presorted samples", n, N);
+  int criteria = split_criteria;
+  if (criteria != 1 && criteria != 3) criteria = boost_type == 0 ? 3 : 1;  // o_cvboostree.cpp:188-190
+  const bool gini = criteria == 1;
+  cc_status st = eval_device(e);
+  if (st != CC_OK) return st;
+  std::memset(out, 0, sizeof(*out));
+  out->quality = -1.f;
+  const int F = e->presort_f1 - e->presort_f0, var0 = e->presort_f0;  // per-variable outputs are indexed from presort's fi_begin
+  if (per_var_quality)
+    for (int f = 0; f < F; f++) per_var_quality[f] = -1.0;
+  if (per_var_point)
+    for (int f = 0; f < F; f++) per_var_point[f] = -1;
+  if (n <= 1) return CC_OK;  // get_num_valid(vi) <= 1: no variable is searched
+  for (int i = 0; i < n; i++) {
+    if (is_classifier && (class_labels[i] < 0 || class_labels[i] > 1))
+      return set_error(CC_ERR_INVALID_ARG, "cc_eval_find_best_split: class label %d of sample %d is not 0 / 1", class_labels[i], i);
+    if (!(weights[i] >= 0.0)) return set_error(CC_ERR_INVALID_ARG, "cc_eval_find_best_split: weight of sample %d is negative or NaN", i);
+  }
+  std::lock_guard<std::mutex> lk(e->mu);
+  const bool haar = e->type == CC_FEATURE_HAAR;
+  PinnedBuf& pin_in = e->pin_in;
+  PinnedBuf& pin_out = e->pin_out;
+  if (haar) {
+    // per stored sample {w, t}; not in this node: w = -1 (16-B entries) or NaN (8-B entries)
+    const bool idx16 = N <= 65536;
+    const int mode = !is_classifier ? 0 : (gini ? 1 : 2);
+    bool unit_responses = !is_classifier;
+    if (!is_classifier)
+      for (int i = 0; i < n && unit_responses; i++) unit_responses = responses[i] == 1.0f || responses[i] == -1.0f;
+    const size_t lds_cap = 160 * 1024;
+    int tab_kind = 0;
+    if ((is_classifier || unit_responses) && (size_t)N * 8 <= lds_cap)
+      tab_kind = 2;
+    else if ((size_t)N * 16 <= lds_cap)
+      tab_kind = 1;
+    if (std::getenv("CCAMD_SPLIT_GLOBAL_TABLE")) tab_kind = 0;
+    const size_t entry_bytes = tab_kind == 2 ? 8 : 16;
+    CC_HIP(pin_in.ensure((size_t)N * entry_bytes));
+    std::vector<uint8_t> seen((size_t)N, 0);
+    SplitEntry* tab16 = static_cast<SplitEntry*>(pin_in.p);
+    double* tab8 = static_cast<double*>(pin_in.p);
+    for (int g = 0; g < N; g++) {
+      if (tab_kind == 2)
+        tab8[g] = std::numeric_limits<double>::quiet_NaN();
+      else
+        tab16[g] = SplitEntry{-1.0, 0.0};
+    }
+    for (int i = 0; i < n; i++) {
+      const int g = sample_idx ? sample_idx[i] : i;
+      if (g < 0 || g >= N) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_find_best_split: sample index %d outside the %d presorted samples", g, N);
+      if (seen[(size_t)g]) return set_error(CC_ERR_INVALID_ARG, "cc_eval_find_best_split: sample %d occurs twice in the node", g);
+      seen[(size_t)g] = 1;
+      const double w = weights[i];
+      if (tab_kind == 2)
+        tab8[g] = is_classifier ? (class_labels[i] ? -w : w) : responses[i] * w;
+      else {
+        tab16[g].w = w;
+        tab16[g].t = is_classifier ? (double)class_labels[i] : responses[i] * w;
+      }
+    }
+    const size_t groups = ((size_t)F + 63) / 64, fpad = groups * 64;
+    CC_HIP(e->d_split_tab.ensure((size_t)N * 2));
+    CC_HIP(e->d_split_out.ensure(fpad * 3));  // best_val (8 B) + best_i, vl, vr (4 B each) + slack
+    CC_HIP(hipMemcpyAsync(e->d_split_tab.p, pin_in.p, (size_t)N * entry_bytes, hipMemcpyHostToDevice, e->stream));
+    SplitOrdArgs A;
+    A.sv = e->d_sorted_val.p;
+    A.si = idx16 ? (const void*)e->d_sorted_idx16.p : (const void*)e->d_sorted_idx32.p;
+    A.tab = reinterpret_cast<const SplitEntry*>(e->d_split_tab.p);
+    A.n_pre = N;
+    A.n_vars = F;
+    A.n_groups = (int)groups;
+    A.w_total0 = weights[n];
+    A.w_total1 = weights[n + 1];
+    A.rsum0 = node_value * weights[n];
+    A.best_val = e->d_split_out.p;
+    A.best_i = reinterpret_cast<int*>(e->d_split_out.p + fpad);
+    A.best_vl = reinterpret_cast<float*>(A.best_i + fpad);
+    A.best_vr = A.best_vl + fpad;
+    A.dbg_nogather = std::getenv("CCAMD_DEBUG_SPLIT_NOGATHER") ? 1 : 0;
+    // wavefronts per block: with the table in LDS one block owns a CU, so spread the groups evenly over the CUs
+    // (162 336 variables = 2 537 groups -> 254 blocks of 10 wavefronts on 256 CUs); from global memory, one wavefront
+    int wpb = 1;
+    if (tab_kind != 0) {
+      hipDeviceProp_t prop;
+      CC_HIP(hipGetDeviceProperties(&prop, e->device));
+      const int cus = std::max(1, prop.multiProcessorCount);
+      wpb = (int)std::min<size_t>(16, std::max<size_t>(1, (groups + cus - 1) / cus));
+      if (const char* v = std::getenv("CCAMD_SPLIT_WAVES")) wpb = std::max(1, std::min(16, std::atoi(v)));
+    }
+    const unsigned blocks = (unsigned)((groups + wpb - 1) / wpb);
+    const size_t lds = tab_kind == 0 ? 0 : (size_t)N * entry_bytes;
+    (void)hipEventRecord(e->ev_a, e->stream);
+#define CC_LAUNCH_ORD3(M, TI, T)                                                                                              \
+  do {                                                                                                                        \
+    if (lds > 64 * 1024)                                                                                                      \
+      CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_split_ord<M, TI, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_split_ord<M, TI, T>), dim3(blocks), dim3(64 * wpb), lds, e->stream, A);                             \
+  } while (0)
+#define CC_LAUNCH_ORD2(M, TI)          \
+  do {                                 \
+    if (tab_kind == 0)                 \
+      CC_LAUNCH_ORD3(M, TI, 0);        \
+    else if (tab_kind == 1)            \
+      CC_LAUNCH_ORD3(M, TI, 1);        \
+    else                               \
+      CC_LAUNCH_ORD3(M, TI, 2);        \
+  } while (0)
+#define CC_LAUNCH_ORD(M)               \
+  do {                                 \
+    if (idx16)                         \
+      CC_LAUNCH_ORD2(M, uint16_t);     \
+    else                               \
+      CC_LAUNCH_ORD2(M, int32_t);      \
+  } while (0)
+    if (mode == 0)
+      CC_LAUNCH_ORD(0);
+    else if (mode == 1)
+      CC_LAUNCH_ORD(1);
+    else
+      CC_LAUNCH_ORD(2);
+#undef CC_LAUNCH_ORD
+#undef CC_LAUNCH_ORD2
+#undef CC_LAUNCH_ORD3
+    (void)hipEventRecord(e->ev_b, e->stream);
+    CC_HIP(hipGetLastError());
+    CC_HIP(pin_out.ensure(fpad * 24));
+    CC_HIP(hipMemcpyAsync(pin_out.p, e->d_split_out.p, fpad * 20, hipMemcpyDeviceToHost, e->stream));
+    CC_HIP(hipStreamSynchronize(e->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_ms = ms;
+    const double* bv = static_cast<const double*>(pin_out.p);
+    const int* bi = reinterpret_cast<const int*>(bv + fpad);
+    const float* vl = reinterpret_cast<const float*>(bi + fpad);
+    const float* vr = vl + fpad;
+    // the winner, variable by variable as DTreeBestSplitFinder::operator() does (o_cvdtree.cpp:320-342): a variable
+    // reports a split only if it beats the best quality so far (a float), and replaces it only if its own quality,
+    // rounded to float, is larger
+    float best_q = -1.f;
+    int winner = -1;
+    for (int f = 0; f < F; f++) {
+      if (per_var_quality) per_var_quality[f] = bi[f] >= 0 ? bv[f] : -1.0;
+      if (per_var_point) per_var_point[f] = bi[f];
+      if (bi[f] < 0 || !((double)best_q < bv[f])) continue;
+      const float q = (float)bv[f];
+      if (best_q < q) {
+        best_q = q;
+        winner = f;
+      }
+    }
+    if (winner >= 0 && best_q > 0) {  // o_cvdtree.cpp:351
+      out->found = 1;
+      out->var_idx = var0 + winner;
+      out->quality = best_q;
+      out->ord_c = (vl[winner] + vr[winner]) * 0.5f;
+      out->split_point = bi[winner];
+    }
+    return CC_OK;
+  }
+  // ---- categorical (LBP) ----
+  CC_HIP(pin_in.ensure((size_t)n * (sizeof(SplitEntry) + 4)));
+  SplitEntry* tab = static_cast<SplitEntry*>(pin_in.p);
+  int32_t* idx_host = reinterpret_cast<int32_t*>(tab + n);
+  {
+    std::vector<uint8_t> seen((size_t)N, 0);
+    for (int i = 0; i < n; i++) {
+      const int g = sample_idx ? sample_idx[i] : i;
+      if (g < 0 || g >= N) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_find_best_split: sample index %d outside the %d presorted samples", g, N);
+      if (seen[(size_t)g]) return set_error(CC_ERR_INVALID_ARG, "cc_eval_find_best_split: sample %d occurs twice in the node", g);
+      seen[(size_t)g] = 1;
+      idx_host[i] = g;
+      tab[i].w = weights[i];
+      tab[i].t = is_classifier ? (double)class_labels[i] : responses[i] * weights[i];
+    }
+  }
+  CC_HIP(e->d_split_tab.ensure((size_t)n * 2));
+  CC_HIP(e->d_split_idx.ensure((size_t)n));
+  const size_t hist_n = (size_t)F * 256 * 2;
+  CC_HIP(e->d_split_out.ensure(hist_n));
+  CC_HIP(hipMemcpyAsync(e->d_split_tab.p, tab, (size_t)n * sizeof(SplitEntry), hipMemcpyHostToDevice, e->stream));
+  CC_HIP(hipMemcpyAsync(e->d_split_idx.p, idx_host, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  (void)hipEventRecord(e->ev_a, e->stream);
+  if (is_classifier)
+    hipLaunchKernelGGL(k_split_cat<true>, dim3((unsigned)F), dim3(256), 0, e->stream, e->d_codes.p, N, sample_idx ? e->d_split_idx.p : nullptr,
+                       reinterpret_cast<const SplitEntry*>(e->d_split_tab.p), n, e->d_split_out.p);
+  else
+    hipLaunchKernelGGL(k_split_cat<false>, dim3((unsigned)F), dim3(256), 0, e->stream, e->d_codes.p, N, sample_idx ? e->d_split_idx.p : nullptr,
+                       reinterpret_cast<const SplitEntry*>(e->d_split_tab.p), n, e->d_split_out.p);
+  (void)hipEventRecord(e->ev_b, e->stream);
+  CC_HIP(hipGetLastError());
+  CC_HIP(pin_out.ensure(hist_n * 8));
+  CC_HIP(hipMemcpyAsync(pin_out.p, e->d_split_out.p, hist_n * 8, hipMemcpyDeviceToHost, e->stream));
+  CC_HIP(hipStreamSynchronize(e->stream));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_ms = ms;
+  const double* hist = static_cast<const double*>(pin_out.p);
+  std::vector<CatSplit> res((size_t)F);
+  {
+    const int nt = std::max(1, std::min<int>({(int)std::thread::hardware_concurrency(), 16, F / 64 + 1}));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+      th.emplace_back([&, t]() {
+        for (int f = t; f < F; f += nt) split_categories(hist + (size_t)f * 512, 256, is_classifier, gini, res[(size_t)f]);
+      });
+    for (auto& x : th) x.join();
+  }
+  float best_q = -1.f;
+  int winner = -1;
+  for (int f = 0; f < F; f++) {
+    const CatSplit& r = res[(size_t)f];
+    if (per_var_quality) per_var_quality[f] = r.found ? r.quality : -1.0;
+    if (per_var_point) per_var_point[f] = r.found ? r.n_left - 1 : -1;
+    if (!r.found || !((double)best_q < r.quality)) continue;
+    const float q = (float)r.quality;
+    if (best_q < q) {
+      best_q = q;
+      winner = f;
+    }
+  }
+  if (winner >= 0 && best_q > 0) {
+    out->found = 1;
+    out->var_idx = var0 + winner;
+    out->quality = best_q;
+    std::memcpy(out->subset, res[(size_t)winner].subset, sizeof(out->subset));
+  }
+  return CC_OK;
+}
+
+}  // extern "C"

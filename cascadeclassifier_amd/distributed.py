@@ -47,3 +47,46 @@ def gather_detections(per_frame: list[np.ndarray], device=None, group=None) -> l
             out.append(p[o:o + 4 * int(c)].reshape(-1, 4).copy())
             o += 4 * int(c)
     return out
+
+
+# ---- training side: variables shard across ranks ------------------------------------------------
+_SPLIT_WORDS = 13  # found, var_idx, quality bits, ord_c bits, split_point, subset[8]
+
+
+def pick_split(per_shard: list[dict]) -> dict:
+    """The reference scans variables in catalog order and keeps the first one whose float quality is strictly larger than
+    the best so far (o_cvdtree.cpp:320-342), i.e. the first variable with the largest float quality. Shards are
+    contiguous catalog ranges in rank order, so the global winner is the shard result with the largest quality, the
+    lowest rank winning ties."""
+    best = None
+    for s in per_shard:
+        if s["found"] and (best is None or s["quality"] > best["quality"]):
+            best = s
+    return best if best is not None else dict(per_shard[0], found=False)
+
+
+def find_best_split_sharded(evaluator, weights, device=None, group=None, **kw) -> dict:
+    """evaluator has presorted this rank's variable range (CvFeatureEvaluator.presort(n, *shard_range(F, rank, world)));
+    every rank passes the same node. One all_gather of 52 bytes per rank (the arg-max exchange of SURVEY §8e)."""
+    import torch
+    import torch.distributed as dist
+
+    local = evaluator.find_best_split(weights, **kw)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    words = np.zeros(_SPLIT_WORDS, np.int32)
+    words[0], words[1], words[4] = int(local["found"]), local["var_idx"], local["split_point"]
+    words[2] = np.float32(local["quality"]).view(np.int32)
+    words[3] = np.float32(local["ord_c"]).view(np.int32)
+    words[5:] = local["subset"]
+    mine = torch.from_numpy(words).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    shards = []
+    for p in parts:
+        p = p.cpu().numpy()
+        shards.append({"found": bool(p[0]), "var_idx": int(p[1]), "quality": p[2:3].view(np.float32)[0], "ord_c": p[3:4].view(np.float32)[0],
+                       "split_point": int(p[4]), "subset": p[5:].copy()})
+    return pick_split(shards)

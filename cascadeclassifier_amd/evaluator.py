@@ -13,6 +13,10 @@ HAAR, LBP, HOG = L.CC_FEATURE_HAAR, L.CC_FEATURE_LBP, L.CC_FEATURE_HOG
 BASIC, CORE, ALL = L.CC_HAAR_BASIC, L.CC_HAAR_CORE, L.CC_HAAR_ALL
 
 
+BOOST_DISCRETE, BOOST_REAL, BOOST_LOGIT, BOOST_GENTLE = 0, 1, 2, 3  # CvBoost types (boost.h)
+SPLIT_DEFAULT, SPLIT_GINI, SPLIT_MISCLASS, SPLIT_SQERR = 0, 1, 3, 4
+
+
 def _vp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -113,6 +117,39 @@ class CvFeatureEvaluator:
         out = np.empty(ns, np.uint8)
         L.check(L.lib().cc_eval_predict_cascade(self._e, cascade._c, _vp(idx), ns, _vp(out)))
         return out
+
+    # ---- best-split search of a boosted-tree node (CvDTree::find_best_split, o_cvdtree.cpp:313-357)
+    def presort(self, n_samples=None, fi_begin=0, fi_end=None):
+        """Evaluate features [fi_begin, fi_end) (default: all) on stored samples [0, n_samples) and keep the sorted
+        order (Haar) / the category codes (LBP) resident on the device; call again whenever the stored samples change."""
+        n = self.maxSampleCount if n_samples is None else int(n_samples)
+        self._presorted = (int(fi_begin), self.getNumFeatures() if fi_end is None else int(fi_end))
+        L.check(L.lib().cc_eval_presort_range(self._e, self._presorted[0], self._presorted[1], n))
+
+    def find_best_split(self, weights, *, responses=None, class_labels=None, sample_idx=None, node_value=0.0,
+                        boost_type=BOOST_GENTLE, split_criteria=0, per_var=False):
+        """weights: n + 2 doubles (CvBoostTree::calc_node_value's subtree weights: per sample, then the totals).
+        Returns a dict (found, var_idx, quality, ord_c, split_point, subset); with per_var=True also the per-variable
+        best qualities (float64) and split points."""
+        w = np.ascontiguousarray(weights, np.float64)
+        n = len(w) - 2
+        idx = None if sample_idx is None else np.ascontiguousarray(sample_idx, np.int32)
+        if idx is not None and len(idx) != n:
+            raise ValueError("weights must hold len(sample_idx) + 2 values")
+        resp = None if responses is None else np.ascontiguousarray(responses, np.float32)
+        lab = None if class_labels is None else np.ascontiguousarray(class_labels, np.int32)
+        for a in (resp, lab):
+            if a is not None and len(a) != n:
+                raise ValueError("responses / class_labels must hold one value per node sample")
+        sp = L.Split()
+        nf = self._presorted[1] - self._presorted[0] if getattr(self, "_presorted", None) else self.getNumFeatures()
+        q = np.empty(nf, np.float64) if per_var else None
+        pt = np.empty(nf, np.int32) if per_var else None
+        L.check(L.lib().cc_eval_find_best_split(self._e, _vp(idx), n, _vp(w), _vp(resp), _vp(lab), float(node_value), int(boost_type),
+                                                int(split_criteria), C.byref(sp), _vp(q), _vp(pt)))
+        out = {"found": bool(sp.found), "var_idx": sp.var_idx, "quality": np.float32(sp.quality), "ord_c": np.float32(sp.ord_c),
+               "split_point": sp.split_point, "subset": np.array(sp.subset[:], np.int32)}
+        return (out, q, pt) if per_var else out
 
     def getNumFeatures(self) -> int:
         return L.lib().cc_eval_num_features(self._e)

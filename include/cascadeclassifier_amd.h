@@ -299,6 +299,53 @@ CC_API cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width,
                                  uint8_t* pass, int64_t cap, int64_t* n_windows, uint8_t* pixels, int64_t* keep_index,
                                  int max_keep, int* n_keep);
 
+/* ============================================================================================
+ * 6. Best-split search of a boosted-tree node on the device.
+ *    Replaces CvDTree::find_best_split (traincascade/lib/src/o_cvdtree.cpp:313-357) and the per-variable searches it
+ *    calls, CvBoostTree::find_split_ord_class / find_split_cat_class / find_split_ord_reg / find_split_cat_reg
+ *    (o_cvboostree.cpp:151-247, 249-359, 361-426, 428-516), on the variable data CvCascadeBoostTrainData::
+ *    get_ord_var_data / get_cat_var_data deliver (o_cvcascadeboosttraindata.cpp:403-482).
+ *
+ *    cc_eval_presort evaluates EVERY feature on stored samples [0, n_samples) once and keeps the result resident in
+ *    HBM: for Haar the per-feature sorted order (values + sample indices; the reference's FeatureValAndIdxPrecalc,
+ *    o_cvcascadeboosttraindata.cpp:535-556, limited there to the -precalcValBufSize / -precalcIdxBufSize budgets), for
+ *    LBP the category codes. 6 bytes per (feature, sample): 19.5 GB for BASIC 24x24 x 20 000 samples. Call it after
+ *    the stage's samples are in place (setImage / cc_eval_set_images) and again whenever they change.
+ *
+ *    cc_eval_find_best_split then searches one node: sample_idx are the node's stored-sample slots in node order (NULL
+ *    = 0..n-1; no duplicates), weights the n + 2 "subtree weights" of CvBoostTree::calc_node_value
+ *    (o_cvboostree.cpp:657-732: w[i], then the totals w[n], w[n+1]), responses the ordered responses (regression
+ *    trees: LOGIT / GENTLE boost) or class_labels the 0/1 labels (DISCRETE / REAL boost), node_value = node->value.
+ *    boost_type / split_criteria take CvBoost's values (boost.h: DISCRETE 0, REAL 1, LOGIT 2, GENTLE 3; DEFAULT 0,
+ *    GINI 1, MISCLASS 3, SQERR 4) with the reference's defaulting rule (o_cvboostree.cpp:188-190).
+ *    The arithmetic is the reference's, operation by operation, in double: one thread walks one variable's samples in
+ *    sorted order. Equal feature values are taken in increasing sample-index order (the reference's std::sort leaves
+ *    their order unspecified); categories are ordered with the same std::sort call as the reference. The winner over
+ *    variables is chosen in variable order with the reference's float comparisons (o_cvdtree.cpp:340-341,351).
+ *    out->found = 0 when no split has quality > 0 (find_best_split returns NULL). Optional per-variable results (NULL to
+ *    skip): per_var_quality[vi] = best quality of variable vi on its own (-1 if it has no split),
+ *    per_var_point[vi] = split_point (ordered) or number of categories sent left - 1 (categorical).
+ * ============================================================================================ */
+typedef struct cc_split {
+  int32_t found;       /* 1 if a split was found */
+  int32_t var_idx;     /* feature index (catalog order) */
+  float quality;
+  float ord_c;         /* ordered variables: threshold, samples with value <= ord_c go left */
+  int32_t split_point; /* ordered variables: position of the last left sample in the node's sorted order */
+  int32_t subset[8];   /* categorical variables: bit c set = category c goes left */
+} cc_split;
+/*    Multi-GPU: variables shard across processes: cc_eval_presort_range keeps only variables
+ *    [fi_begin, fi_end) on this device; cc_eval_find_best_split then searches that range (var_idx stays a catalog index,
+ *    per_var_* arrays hold fi_end - fi_begin entries). Because the reference's winner is the first variable with the
+ *    largest float quality, the global winner is the shard result with the largest quality, lowest shard first.
+ */
+CC_API cc_status cc_eval_presort(cc_evaluator* e, int n_samples);
+CC_API cc_status cc_eval_presort_range(cc_evaluator* e, int fi_begin, int fi_end, int n_samples);
+CC_API cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, int n, const double* weights,
+                                         const float* responses, const int32_t* class_labels, double node_value,
+                                         int boost_type, int split_criteria, cc_split* out, double* per_var_quality,
+                                         int32_t* per_var_point);
+
 #ifdef __cplusplus
 }
 #endif

@@ -886,4 +886,308 @@ ORC_API int64_t orc_negmine_image(const OrcCascade* c, const uint8_t* src, int c
   return n;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Best-split search of one tree node: CvDTree::find_best_split (o_cvdtree.cpp:313-357, whose
+// parallel_reduce is the serial stand-in of o_blockedrange.h:41-47, i.e. ONE range over all variables) calling
+//   CvBoostTree::find_split_ord_class  o_cvboostree.cpp:151-247   (DISCRETE / REAL boost, Haar)
+//   CvBoostTree::find_split_cat_class  o_cvboostree.cpp:249-359   (DISCRETE / REAL boost, LBP)
+//   CvBoostTree::find_split_ord_reg    o_cvboostree.cpp:361-426   (LOGIT / GENTLE boost, Haar)
+//   CvBoostTree::find_split_cat_reg    o_cvboostree.cpp:428-516   (LOGIT / GENTLE boost, LBP)
+// on the variable data CvCascadeBoostTrainData::get_ord_var_data / get_cat_var_data deliver for a node
+// (o_cvcascadeboosttraindata.cpp:403-482; no missing values in cascade training, so n1 == n).
+//
+// vals: [F][n] feature values of the node's samples in node order (the evaluator's operator(), computed by
+// orc_*_eval_batch). The reference sorts each ordered row with std::sort + LessThanIdx, which leaves the order of equal
+// values unspecified; this restatement (and the product) take equal values in increasing `tie_key` order (the stored
+// sample index), one of the orders std::sort may produce. Categories are sorted exactly as the reference does
+// (std::sort on pointers with LessThanPtr). weights: n + 2 doubles, the "subtree weights" of calc_node_value
+// (o_cvboostree.cpp:657-732): w[i] per node sample, w[n] and w[n+1] the totals.
+// boost_type: 0 DISCRETE, 1 REAL, 2 LOGIT, 3 GENTLE; split_criteria: 0 DEFAULT, 1 GINI, 3 MISCLASS, 4 SQERR (boost.h).
+// ---------------------------------------------------------------------------------------------
+struct OrcSplit {
+  int32_t found, var_idx;
+  float quality, ord_c;
+  int32_t split_point;
+  int32_t subset[8];
+};
+
+namespace {
+
+struct LessIdxTie {
+  const float* v;
+  const int32_t* key;
+  bool operator()(int a, int b) const { return v[a] < v[b] || (!(v[b] < v[a]) && key[a] < key[b]); }
+};
+template <typename T>
+struct LessThanPtrT {
+  bool operator()(T* a, T* b) const { return *a < *b; }
+};
+
+// one variable; returns false when no split beats init_quality
+bool split_ord_reg(const float* values, const int* indices, int n, const double* weights, const float* responses,
+                   double node_value, float init_quality, OrcSplit& sp) {
+  const float epsilon = 1.1920929e-07f * 2;  // FLT_EPSILON * 2
+  int best_i = -1;
+  double L = 0, R = weights[n];
+  double best_val = init_quality, lsum = 0, rsum = node_value * R;
+  for (int i = 0; i < n - 1; i++) {
+    int idx = indices[i];
+    double w = weights[idx];
+    double t = responses[idx] * w;
+    L += w;
+    R -= w;
+    lsum += t;
+    rsum -= t;
+    if (values[i] + epsilon < values[i + 1]) {
+      double val = (lsum * lsum * R + rsum * rsum * L) / (L * R);
+      if (best_val < val) {
+        best_val = val;
+        best_i = i;
+      }
+    }
+  }
+  if (best_i < 0) return false;
+  sp.ord_c = (values[best_i] + values[best_i + 1]) * 0.5f;
+  sp.split_point = best_i;
+  sp.quality = (float)best_val;
+  return true;
+}
+
+bool split_ord_class(const float* values, const int* indices, int n, const double* weights, const int32_t* responses,
+                     int criteria, float init_quality, OrcSplit& sp) {
+  const float epsilon = 1.1920929e-07f * 2;
+  const double* rcw0 = weights + n;
+  double lcw[2] = {0, 0}, rcw[2] = {rcw0[0], rcw0[1]};
+  int best_i = -1;
+  double best_val = init_quality;
+  if (criteria == 1) {  // GINI
+    double L = 0, R = rcw[0] + rcw[1];
+    double lsum2 = 0, rsum2 = rcw[0] * rcw[0] + rcw[1] * rcw[1];
+    for (int i = 0; i < n - 1; i++) {
+      int idx = indices[i];
+      double w = weights[idx], w2 = w * w;
+      idx = responses[idx];
+      L += w;
+      R -= w;
+      double lv = lcw[idx], rv = rcw[idx];
+      lsum2 += 2 * lv * w + w2;
+      rsum2 -= 2 * rv * w - w2;
+      lcw[idx] = lv + w;
+      rcw[idx] = rv - w;
+      if (values[i] + epsilon < values[i + 1]) {
+        double val = (lsum2 * R + rsum2 * L) / (L * R);
+        if (best_val < val) {
+          best_val = val;
+          best_i = i;
+        }
+      }
+    }
+  } else {  // MISCLASS
+    for (int i = 0; i < n - 1; i++) {
+      int idx = indices[i];
+      double w = weights[idx];
+      idx = responses[idx];
+      lcw[idx] += w;
+      rcw[idx] -= w;
+      if (values[i] + epsilon < values[i + 1]) {
+        double val = lcw[0] + rcw[1], val2 = lcw[1] + rcw[0];
+        val = val > val2 ? val : val2;
+        if (best_val < val) {
+          best_val = val;
+          best_i = i;
+        }
+      }
+    }
+  }
+  if (best_i < 0) return false;
+  sp.ord_c = (values[best_i] + values[best_i + 1]) * 0.5f;
+  sp.split_point = best_i;
+  sp.quality = (float)best_val;
+  return true;
+}
+
+bool split_cat_reg(const int* cat_labels, int n, int mi, const double* weights, const float* responses,
+                   float init_quality, OrcSplit& sp) {
+  std::vector<double> sum_buf(mi + 1, 0.0), cnt_buf(mi + 1, 0.0);
+  double* sum = sum_buf.data() + 1;
+  double* counts = cnt_buf.data() + 1;
+  std::vector<double*> sum_ptr(mi);
+  double L = 0, R = 0, best_val = init_quality, lsum = 0, rsum = 0;
+  int best_subset = -1;
+  for (int i = 0; i < n; i++) {
+    int idx = cat_labels[i];
+    double w = weights[i];
+    double s = sum[idx] + responses[i] * w;
+    double nc = counts[idx] + w;
+    sum[idx] = s;
+    counts[idx] = nc;
+  }
+  for (int i = 0; i < mi; i++) {
+    R += counts[i];
+    rsum += sum[i];
+    sum[i] = std::fabs(counts[i]) > 2.2204460492503131e-16 ? sum[i] / counts[i] : 0;
+    sum_ptr[i] = sum + i;
+  }
+  std::sort(sum_ptr.begin(), sum_ptr.end(), LessThanPtrT<double>());
+  for (int i = 0; i < mi; i++) sum[i] *= counts[i];
+  for (int subset_i = 0; subset_i < mi - 1; subset_i++) {
+    int idx = (int)(sum_ptr[subset_i] - sum);
+    double ni = counts[idx];
+    if (ni > 1.1920929e-07f) {
+      double s = sum[idx];
+      lsum += s;
+      L += ni;
+      rsum -= s;
+      R -= ni;
+      if (L > 1.1920929e-07f && R > 1.1920929e-07f) {
+        double val = (lsum * lsum * R + rsum * rsum * L) / (L * R);
+        if (best_val < val) {
+          best_val = val;
+          best_subset = subset_i;
+        }
+      }
+    }
+  }
+  if (best_subset < 0) return false;
+  sp.quality = (float)best_val;
+  std::memset(sp.subset, 0, sizeof(sp.subset));
+  for (int i = 0; i <= best_subset; i++) {
+    int idx = (int)(sum_ptr[i] - sum);
+    sp.subset[idx >> 5] |= 1 << (idx & 31);
+  }
+  return true;
+}
+
+bool split_cat_class(const int* cat_labels, int n, int mi, const double* weights, const int32_t* responses, int criteria,
+                     float init_quality, OrcSplit& sp) {
+  std::vector<double> cjk_buf(2 * mi + 2, 0.0);
+  double* cjk = cjk_buf.data() + 2;
+  std::vector<double*> dbl_ptr(mi);
+  double lcw[2] = {0, 0}, rcw[2] = {0, 0};
+  double L = 0, R;
+  double best_val = init_quality;
+  int best_subset = -1;
+  for (int i = 0; i < n; i++) {
+    double w = weights[i];
+    int j = cat_labels[i];
+    int k = responses[i];
+    cjk[j * 2 + k] += w;
+  }
+  for (int j = 0; j < mi; j++) {
+    rcw[0] += cjk[j * 2];
+    rcw[1] += cjk[j * 2 + 1];
+    dbl_ptr[j] = cjk + j * 2 + 1;
+  }
+  R = rcw[0] + rcw[1];
+  std::sort(dbl_ptr.begin(), dbl_ptr.end(), LessThanPtrT<double>());
+  for (int subset_i = 0; subset_i < mi - 1; subset_i++) {
+    int idx = (int)(dbl_ptr[subset_i] - cjk) / 2;
+    const double* crow = cjk + idx * 2;
+    double w0 = crow[0], w1 = crow[1];
+    double weight = w0 + w1;
+    if (weight < 1.1920929e-07f) continue;
+    lcw[0] += w0;
+    rcw[0] -= w0;
+    lcw[1] += w1;
+    rcw[1] -= w1;
+    if (criteria == 1) {
+      double lsum2 = lcw[0] * lcw[0] + lcw[1] * lcw[1];
+      double rsum2 = rcw[0] * rcw[0] + rcw[1] * rcw[1];
+      L += weight;
+      R -= weight;
+      if (L > 1.1920929e-07f && R > 1.1920929e-07f) {
+        double val = (lsum2 * R + rsum2 * L) / (L * R);
+        if (best_val < val) {
+          best_val = val;
+          best_subset = subset_i;
+        }
+      }
+    } else {
+      double val = lcw[0] + rcw[1];
+      double val2 = lcw[1] + rcw[0];
+      val = val > val2 ? val : val2;
+      if (best_val < val) {
+        best_val = val;
+        best_subset = subset_i;
+      }
+    }
+  }
+  if (best_subset < 0) return false;
+  sp.quality = (float)best_val;
+  std::memset(sp.subset, 0, sizeof(sp.subset));
+  for (int i = 0; i <= best_subset; i++) {
+    int idx = (int)(dbl_ptr[i] - cjk) >> 1;
+    sp.subset[idx >> 5] |= 1 << (idx & 31);
+  }
+  return true;
+}
+
+}  // namespace
+
+// per_feature_quality (nullable, F floats): the quality find_split_* reports for variable vi when called with
+// init_quality = -1 on its own (NaN-free marker -1 when it finds none); per_feature_point likewise (split_point, or the
+// number of categories sent left - 1).
+ORC_API void orc_find_best_split(const float* vals, int F, int n, int categorical, int mi, const int32_t* tie_key,
+                                 const double* weights, const float* responses, const int32_t* class_labels,
+                                 double node_value, int boost_type, int split_criteria, OrcSplit* out,
+                                 float* per_feature_quality, int32_t* per_feature_point) {
+  const bool is_classifier = boost_type == 0 || boost_type == 1;
+  int criteria = split_criteria;
+  if (criteria != 1 && criteria != 3) criteria = boost_type == 0 ? 3 : 1;  // o_cvboostree.cpp:188-190
+  OrcSplit best;
+  std::memset(&best, 0, sizeof(best));
+  best.quality = -1;  // DTreeBestSplitFinder ctor, o_cvdtree.cpp:291
+  std::vector<int> order(n), labels(n);
+  std::vector<float> sorted(n);
+  for (int vi = 0; vi < F; vi++) {
+    const float* row = vals + (size_t)vi * n;
+    if (n <= 1) continue;  // get_num_valid(vi) <= 1
+    OrcSplit sp;
+    std::memset(&sp, 0, sizeof(sp));
+    OrcSplit alone;
+    std::memset(&alone, 0, sizeof(alone));
+    bool res, res_alone = false;
+    if (!categorical) {
+      for (int i = 0; i < n; i++) order[i] = i;
+      std::sort(order.begin(), order.end(), LessIdxTie{row, tie_key});
+      for (int i = 0; i < n; i++) sorted[i] = row[order[i]];
+      if (is_classifier) {
+        res = split_ord_class(sorted.data(), order.data(), n, weights, class_labels, criteria, best.quality, sp);
+        if (per_feature_quality) res_alone = split_ord_class(sorted.data(), order.data(), n, weights, class_labels, criteria, -1.f, alone);
+      } else {
+        res = split_ord_reg(sorted.data(), order.data(), n, weights, responses, node_value, best.quality, sp);
+        if (per_feature_quality) res_alone = split_ord_reg(sorted.data(), order.data(), n, weights, responses, node_value, -1.f, alone);
+      }
+    } else {
+      for (int i = 0; i < n; i++) labels[i] = (int)row[i];  // get_cat_var_data, o_cvcascadeboosttraindata.cpp:464-482
+      if (is_classifier) {
+        res = split_cat_class(labels.data(), n, mi, weights, class_labels, criteria, best.quality, sp);
+        if (per_feature_quality) res_alone = split_cat_class(labels.data(), n, mi, weights, class_labels, criteria, -1.f, alone);
+      } else {
+        res = split_cat_reg(labels.data(), n, mi, weights, responses, best.quality, sp);
+        if (per_feature_quality) res_alone = split_cat_reg(labels.data(), n, mi, weights, responses, -1.f, alone);
+      }
+      if (res_alone) {
+        int cnt = 0;
+        for (int k = 0; k < 8; k++) cnt += __builtin_popcount((unsigned)alone.subset[k]);
+        alone.split_point = cnt - 1;
+      }
+    }
+    if (per_feature_quality) {
+      per_feature_quality[vi] = res_alone ? alone.quality : -1.f;
+      per_feature_point[vi] = res_alone ? alone.split_point : -1;
+    }
+    if (res && best.quality < sp.quality) {  // o_cvdtree.cpp:340-341
+      sp.var_idx = vi;
+      sp.found = 1;
+      best = sp;
+    }
+  }
+  if (!(best.quality > 0)) {  // o_cvdtree.cpp:351
+    std::memset(&best, 0, sizeof(best));
+    best.quality = -1;
+  }
+  *out = best;
+}
+
 ORC_API int orc_version() { return 1; }

@@ -350,3 +350,27 @@ def negmine_image(c: Cascade, img: np.ndarray, ox=0, oy=0, max_keep=64):
     n = lib().orc_negmine_image(C.byref(cs), _p(img), w, h, w, int(ox), int(oy), _p(flags), C.c_int64(cap), _p(pix), _p(idx),
                                 int(max_keep), C.byref(nk))
     return flags[:n].copy(), pix[:nk.value].copy(), idx[:nk.value].copy()
+
+
+# ------------------------------------------------------------------ split search
+SPLIT_DTYPE = np.dtype([("found", "<i4"), ("var_idx", "<i4"), ("quality", "<f4"), ("ord_c", "<f4"), ("split_point", "<i4"),
+                        ("subset", "<i4", (8,))])
+BOOST_DISCRETE, BOOST_REAL, BOOST_LOGIT, BOOST_GENTLE = 0, 1, 2, 3
+
+
+def find_best_split(vals: np.ndarray, weights: np.ndarray, *, categorical=False, responses=None, class_labels=None,
+                    node_value=0.0, boost_type=BOOST_GENTLE, split_criteria=0, tie_key=None, per_feature=False):
+    """vals: [F][n] float32 values of the node's samples in node order; weights: n + 2 doubles (subtree weights)."""
+    vals = np.ascontiguousarray(vals, np.float32)
+    F, n = vals.shape
+    weights = np.ascontiguousarray(weights, np.float64)
+    assert weights.shape == (n + 2,)
+    tie = np.arange(n, dtype=np.int32) if tie_key is None else np.ascontiguousarray(tie_key, np.int32)
+    resp = None if responses is None else np.ascontiguousarray(responses, np.float32)
+    labels = None if class_labels is None else np.ascontiguousarray(class_labels, np.int32)
+    out = np.zeros(1, SPLIT_DTYPE)
+    q = np.empty(F, np.float32) if per_feature else None
+    pt = np.empty(F, np.int32) if per_feature else None
+    lib().orc_find_best_split(_p(vals), F, n, 1 if categorical else 0, 256, _p(tie), _p(weights), _p(resp), _p(labels),
+                              C.c_double(node_value), boost_type, split_criteria, _p(out), _p(q), _p(pt))
+    return (out[0], q, pt) if per_feature else out[0]

@@ -192,6 +192,35 @@ int main(int argc, char** argv) {
       cc_cascade_destroy(c);
     }
   }
+  TEST_CASE("presort + findBestSplit: a Gentle-AdaBoost stump separates left-bright from right-bright windows") {
+    CvHaarFeatureParams params(CvHaarFeatureParams::BASIC);
+    CvHaarEvaluator evaluator;
+    const int n = 40;
+    evaluator.init(&params, n, cv::Size(24, 24));
+    std::vector<float> resp(n);
+    std::vector<double> w(n + 2, 0.0);
+    for (int i = 0; i < n; i++) {
+      cv::Mat img(24, 24, CV_8UC1, cv::Scalar(40));
+      const bool positive = i % 2 == 0;
+      for (int y = 0; y < 24; y++)
+        for (int x = 0; x < 12; x++) img.at<uchar>(y, positive ? x : x + 12) = (uchar)(200 + (i * 7 + y) % 17);
+      evaluator.setImage(img, positive ? 1 : 0, i);
+      resp[i] = positive ? 1.f : -1.f;
+      w[i] = 1.0 / n;
+      w[n] += w[i];
+    }
+    evaluator.presort(n);
+    double value = 0;
+    for (int i = 0; i < n; i++) value += resp[i] * w[i];
+    value *= 1. / w[n];
+    const cc_split sp = evaluator.findBestSplit(nullptr, n, w.data(), resp.data(), nullptr, value, /*GENTLE*/ 3, /*DEFAULT*/ 0);
+    CHECK(sp.found == 1 && sp.quality > 0 && sp.var_idx >= 0 && sp.var_idx < evaluator.getNumFeatures());
+    bool separates = true;
+    const bool pos_left = evaluator(sp.var_idx, 0) <= sp.ord_c;
+    for (int i = 0; i < n; i++) separates = separates && ((evaluator(sp.var_idx, i) <= sp.ord_c) == (i % 2 == 0 ? pos_left : !pos_left));
+    CHECK(separates);
+    CHECK(sp.split_point == n / 2 - 1);
+  }
   if (argc > 1) {
     TEST_CASE("detection tool call shape: CascadeClassifier(file); detectMultiScale(gray, objects, 4, 50)");
     ccamd::CascadeClassifier cascade((std::string(argv[1])));

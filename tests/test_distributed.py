@@ -67,3 +67,68 @@ def test_gather_is_identity_without_process_group():
     rects = [np.array([[1, 2, 3, 4]], np.int32), np.zeros((0, 4), np.int32)]
     out = gather_detections(rects)
     assert len(out) == 2 and out[0].tolist() == [[1, 2, 3, 4]] and out[1].shape == (0, 4)
+
+
+# ---- training side: split search with variables sharded over ranks ------------------------------------------------
+class _FakeShard:
+    """Stands in for an evaluator that presorted one catalog range: returns that range's best split from a table of
+    per-variable float qualities (the device search itself is covered by tests/test_gpu_split.py)."""
+
+    def __init__(self, quality, lo, hi):
+        self.q, self.lo, self.hi = quality, lo, hi
+
+    def find_best_split(self, weights, **kw):
+        q = self.q[self.lo:self.hi]
+        ok = len(q) > 0 and q.max() > 0
+        k = int(np.argmax(q)) if ok else 0  # first occurrence of the maximum
+        return {"found": bool(ok), "var_idx": self.lo + k, "quality": np.float32(q[k]) if ok else np.float32(-1),
+                "ord_c": np.float32(0.25 * (self.lo + k)), "split_point": 7 + self.lo + k, "subset": np.arange(8, dtype=np.int32) * (self.lo + k)}
+
+
+def _qualities(case):
+    rng = np.random.default_rng(case)
+    q = rng.random(101).astype(np.float32)
+    if case == 1:
+        q[[13, 77]] = 2.0  # the same best quality in both shards: the lower variable index must win
+    if case == 2:
+        q[:] = -1.0  # no variable has a split
+    return q
+
+
+def _split_worker(rank, world, port, case, q):
+    import torch.distributed as dist
+
+    from cascadeclassifier_amd.distributed import find_best_split_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    qual = _qualities(case)
+    got = find_best_split_sharded(_FakeShard(qual, *shard_range(len(qual), rank, world)), None)
+    q.put((rank, got["found"], got["var_idx"], float(got["quality"]), float(got["ord_c"]), got["split_point"], got["subset"].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_sharded_split_search_gloo_world2(case):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r[0], r[1:]) for r in (q.get(timeout=120) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    qual = _qualities(case)
+    whole = _FakeShard(qual, 0, len(qual)).find_best_split(None)  # the unsharded scan
+    want = (whole["found"], whole["var_idx"], float(whole["quality"]), float(whole["ord_c"]), whole["split_point"], whole["subset"].tolist())
+    if not whole["found"]:
+        assert not got[0][0] and not got[1][0]
+    else:
+        assert got[0] == want and got[1] == want
