@@ -1153,7 +1153,13 @@ struct cc_detector {
   // plans + workspace
   std::vector<std::unique_ptr<Plan>> plans;
   DevBuf<uint8_t> d_frames, d_pyr;
-  DevBuf<int32_t> d_integ, d_hbuf, d_diag;
+  // The integral images are double-buffered: pyramid + integrals of pass i+1 are built on `front_stream` while the
+  // cascade kernel of pass i (LDS/VALU-bound, leaves wave slots and all of HBM idle) runs on `stream`.
+  DevBuf<int32_t> d_integ[2], d_hbuf, d_diag;
+  hipStream_t front_stream = nullptr;
+  hipEvent_t front_done[2] = {nullptr, nullptr}, eval_done[2] = {nullptr, nullptr}, batch_begin = nullptr;
+  bool eval_pending[2] = {false, false};
+  int overlap_front = 1;
   DevBuf<unsigned long long> d_masks;
   DevBuf<CandRaw> d_cands;
   // Results of a pass are double-buffered so that the host can fetch and group pass i while the device runs pass i+1.
@@ -1178,7 +1184,8 @@ struct cc_detector {
     }
     if (own_stream) (void)hipStreamDestroy(own_stream);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
-    for (auto& e : pass_done)
+    if (front_stream) (void)hipStreamDestroy(front_stream);
+    for (hipEvent_t e : {pass_done[0], pass_done[1], front_done[0], front_done[1], eval_done[0], eval_done[1], batch_begin})
       if (e) (void)hipEventDestroy(e);
     if (h_counts) (void)hipHostFree(h_counts);
   }
@@ -1537,17 +1544,18 @@ struct EvScope {  // records a pair of events around a group of launches when pr
   cc_detector* d;
   int kind;
   hipEvent_t a = nullptr, b = nullptr;
-  EvScope(cc_detector* d_, int kind_) : d(d_), kind(kind_) {
+  hipStream_t st;
+  EvScope(cc_detector* d_, int kind_, hipStream_t st_) : d(d_), kind(kind_), st(st_) {
     if (!d->profiling) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
       a = b = nullptr;
       return;
     }
-    (void)hipEventRecord(a, d->stream);
+    (void)hipEventRecord(a, st);
   }
   ~EvScope() {
     if (!a) return;
-    (void)hipEventRecord(b, d->stream);
+    (void)hipEventRecord(b, st);
     d->events.push_back(TimingEvent{a, b, kind});
   }
 };
@@ -1595,6 +1603,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
                                  size_t frame_stride, bool debug, int slot) {
   const int ns = (int)P->sd.size();
   hipStream_t st = d->stream;
+  hipStream_t fs = d->overlap_front ? d->front_stream : d->stream;  // pyramid + integrals
   const bool haar = d->m.feature_type == CC_FEATURE_HAAR;
   const bool tilt = haar && d->m.has_tilted;
   const int nchan = haar ? (tilt ? 3 : 2) : 1;  // sum, sqsum, tilted
@@ -1602,7 +1611,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   CC_HIP(hipMemsetAsync(d->d_counts[slot].p, 0, 2 * sizeof(int), st));
   if (ns == 0 || nf == 0) return CC_OK;
   CC_HIP(d->d_pyr.ensure(P->pyr_frame_bytes * (size_t)d->max_batch));
-  CC_HIP(d->d_integ.ensure(P->int_frame_elems * (size_t)nchan * (size_t)d->max_batch));
+  CC_HIP(d->d_integ[slot].ensure(P->int_frame_elems * (size_t)nchan * (size_t)d->max_batch));
   CC_HIP(d->d_hbuf.ensure(std::max<size_t>(P->h_frame_elems * (size_t)nchan * (size_t)d->max_batch, 4)));
   if (tilt) CC_HIP(d->d_diag.ensure(P->int_frame_elems * 2 * (size_t)d->max_batch));
   CC_HIP(d->d_masks.ensure(std::max<size_t>(P->mask_frame_words * (size_t)d->max_batch, 1)));
@@ -1614,27 +1623,33 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     CC_HIP(d->d_dbg_sums.ensure((size_t)std::max<long long>(P->windows, 1)));
     CC_HIP(d->d_dbg_visited.ensure((size_t)std::max<long long>(P->windows, 1)));
   }
+  // this slot's integrals may still be read by the cascade kernel launched two passes ago
+  if (fs != st && d->eval_pending[slot]) CC_HIP(hipStreamWaitEvent(fs, d->eval_done[slot], 0));
   {
-    EvScope ev(d, EV_RESIZE);
-    hipLaunchKernelGGL(k_resize, dim3(P->n_resize_blocks, nf), dim3(256), 0, st, dframes, row_stride, frame_stride, P->w,
+    EvScope ev(d, EV_RESIZE, fs);
+    hipLaunchKernelGGL(k_resize, dim3(P->n_resize_blocks, nf), dim3(256), 0, fs, dframes, row_stride, frame_stride, P->w,
                        P->h, d->d_pyr.p, P->pyr_frame_bytes, P->d_sd.p, ns, P->d_resize_first.p, P->d_xofs.p, P->d_xw1.p,
                        P->d_yofs.p, P->d_yw1.p);
   }
   {
-    EvScope ev(d, EV_INTEGRAL);
-    launch_integral(st, haar, d->d_pyr.p, P->pyr_frame_bytes, d->d_integ.p, P->int_frame_elems, nchan, d->d_hbuf.p,
+    EvScope ev(d, EV_INTEGRAL, fs);
+    launch_integral(fs, haar, d->d_pyr.p, P->pyr_frame_bytes, d->d_integ[slot].p, P->int_frame_elems, nchan, d->d_hbuf.p,
                     P->h_frame_elems, P->d_sd.p, ns, P->d_band_first.p, P->n_bands, P->d_col_first.p, P->n_col_blocks, nf);
     if (tilt) {
-      hipLaunchKernelGGL(k_diag_sums, dim3(P->n_diag_blocks, nf, 2), dim3(64), 0, st, d->d_pyr.p, P->pyr_frame_bytes, d->d_diag.p,
+      hipLaunchKernelGGL(k_diag_sums, dim3(P->n_diag_blocks, nf, 2), dim3(64), 0, fs, d->d_pyr.p, P->pyr_frame_bytes, d->d_diag.p,
                          P->int_frame_elems, P->d_sd.p, ns, P->d_diag_first.p);
-      hipLaunchKernelGGL(k_tilted_cols, dim3(P->n_tcol_blocks, nf), dim3(64), 0, st, d->d_pyr.p, P->pyr_frame_bytes, d->d_diag.p,
-                         d->d_integ.p, P->int_frame_elems, nchan, 2, P->d_sd.p, ns, P->d_tcol_first.p);
+      hipLaunchKernelGGL(k_tilted_cols, dim3(P->n_tcol_blocks, nf), dim3(64), 0, fs, d->d_pyr.p, P->pyr_frame_bytes, d->d_diag.p,
+                         d->d_integ[slot].p, P->int_frame_elems, nchan, 2, P->d_sd.p, ns, P->d_tcol_first.p);
     }
   }
+  if (fs != st) {
+    CC_HIP(hipEventRecord(d->front_done[slot], fs));
+    CC_HIP(hipStreamWaitEvent(st, d->front_done[slot], 0));
+  }
   {
-    EvScope ev(d, EV_EVAL);
+    EvScope ev(d, EV_EVAL, st);
     EvalArgs A;
-    A.integ = d->d_integ.p;
+    A.integ = d->d_integ[slot].p;
     A.int_frame_elems = P->int_frame_elems;
     A.nchan = nchan;
     A.tilt_chan = tilt ? 2 : -1;
@@ -1674,8 +1689,12 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
         hipLaunchKernelGGL(k_eval_lbp, dim3(P->n_tiles, nf), dim3(EVAL_THREADS), d->lds, st, A);
     }
   }
+  if (fs != st) {
+    CC_HIP(hipEventRecord(d->eval_done[slot], st));
+    d->eval_pending[slot] = true;
+  }
   {
-    EvScope ev(d, EV_FILTER);
+    EvScope ev(d, EV_FILTER, st);
     hipLaunchKernelGGL(k_filter_candidates, dim3(64), dim3(256), 0, st, d->d_cands.p, d->d_counts[slot].p, d->cand_cap, P->d_sd.p,
                        d->d_masks.p, P->mask_frame_words, d->d_out[slot].p, d->d_counts[slot].p + 1);
     if (debug && P->n_grid_rows)
@@ -1716,6 +1735,15 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     CC_HIP(hipEventCreateWithFlags(&d->pass_done[0], hipEventDisableTiming));
     CC_HIP(hipEventCreateWithFlags(&d->pass_done[1], hipEventDisableTiming));
     CC_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->h_counts), 4 * sizeof(int), hipHostMallocDefault));
+    CC_HIP(hipStreamCreateWithFlags(&d->front_stream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&d->front_done[0], &d->front_done[1], &d->eval_done[0], &d->eval_done[1], &d->batch_begin})
+      CC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    d->overlap_front = std::getenv("CCAMD_NO_FRONT_OVERLAP") ? 0 : 1;
+  }
+  hipStream_t front = d->overlap_front ? d->front_stream : d->stream;
+  if (front != d->stream) {  // frames produced by earlier work on the caller's stream must be complete before the pyramid reads them
+    CC_HIP(hipEventRecord(d->batch_begin, d->stream));
+    CC_HIP(hipStreamWaitEvent(front, d->batch_begin, 0));
   }
   int pass_frames = d->max_batch;
   if (want_results && n_frames >= 2) {  // only the last pass's host work is exposed: use a few passes, not two halves
@@ -1776,7 +1804,7 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       uint8_t* stage = d->d_frames.p + (size_t)slot * ps.fs * (size_t)d->max_batch;
       for (int f = 0; f < ps.nf; f++)
         CC_HIP(hipMemcpy2DAsync(stage + (size_t)f * ps.fs, ps.rs, frames + (size_t)(f0 + f) * frame_stride, row_stride,
-                                (size_t)width, (size_t)height, hipMemcpyHostToDevice, d->stream));
+                                (size_t)width, (size_t)height, hipMemcpyHostToDevice, front));
       ps.dptr = stage;
     }
     stt = run_device_pass(d, P, ps.dptr, ps.nf, ps.rs, ps.fs, debug, slot);
@@ -1790,8 +1818,8 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       }
       prev = ps;
       have_prev = true;
-      slot ^= 1;
     }
+    slot ^= 1;
   }
   if (have_prev) {
     stt = retire(prev);
