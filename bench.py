@@ -133,6 +133,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # windows the scan actually visits (grid windows minus the positions the stage-0 skip rule jumps over), frame 0,
+    # outside the timed region (SURVEY.md §8d asks for it next to the grid count)
+    visited0 = None
+    if rank == 0 and not args.device_only:
+        visited0 = int(clf.debug_windows(frames_host[0], args.scale_factor)[2].sum())
     total_windows = windows_per_frame * B * world * args.steps
     value = total_windows / dt / 1e6
     # average duration of one launch of the cascade kernel (HIP events on the detector's stream) and the frames one
@@ -163,6 +168,7 @@ def main():
             "workload": f"{W}x{H} Haar frontalface detection, full scale pyramid (scaleFactor {args.scale_factor}, minNeighbors "
                         f"{args.min_neighbors}), {len(plan)} scales, {windows_per_frame} grid windows/frame",
             "cascade": os.path.basename(args.cascade) + " (synthetic, stock 25-stage/2913-stump profile)",
+            "visited_windows_frame0": visited0,
             "frames_per_gpu_per_step": B,
             "frame_content": "1/f noise (sigma 40) + 5 pasted face templates",
             "parallelism": f"frames sharded over {world} GPU(s); RCCL gather of detections only",
@@ -199,6 +205,9 @@ def main():
             if last is not None:
                 ok = ok and r.shape == last[i].shape and bool((r == last[i]).all())
         cdt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        orc.detect_multiscale(o, frames_host[0], args.scale_factor, args.min_neighbors, nthreads=1)
+        one = time.perf_counter() - t1
         out["cpu_baseline"] = {
             "value": round(windows_per_frame * nfr / cdt / 1e6, 3),
             "unit": "Mwindows/s",
@@ -207,6 +216,7 @@ def main():
             "sample": f"{nfr} of the same {W}x{H} frames, full detectMultiScale, CPU oracle (restatement of the reference path; "
                       f"OpenCV not installed), {cores} threads over grid rows",
             "seconds": round(cdt, 2),
+            "value_1_thread": round(windows_per_frame / one / 1e6, 3),
             "rectangles_identical_to_gpu": ok if last is not None else None,
         }
     if rank == 0:
