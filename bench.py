@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--scale-factor", type=float, default=1.1)
     ap.add_argument("--min-neighbors", type=int, default=3)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--specialize", type=int, default=7, help="stages compiled into the cascade kernel at load time (hiprtc; 0 = "
+                                                              "table-driven kernel only)")
     ap.add_argument("--device-only", action="store_true", help="time the device pipeline only (no copy-back/grouping)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path on a box with fewer GPUs than ranks)")
@@ -95,6 +97,12 @@ def main():
     clf = cc.CascadeClassifier(args.cascade, device=dev_index, max_batch=B)
     assert not clf.empty(), getattr(clf, "load_error", "")
     inf = clf.info()
+    spec_stages = 0
+    if args.specialize > 0 and inf["feature_type"] == 0 and inf["max_nodes_per_tree"] == 1:
+        try:  # load-time work, outside the timed region; without hiprtc the table-driven kernel stays in use
+            spec_stages = clf.specialize(args.specialize)
+        except cc.CascadeError as e:
+            print(f"[bench] specialisation unavailable: {e}", file=sys.stderr)
     plan = cc.scale_plan(inf["win_w"], inf["win_h"], W, H, args.scale_factor)
     windows_per_frame = int((plan["nx"].astype(np.int64) * plan["ny"]).sum())
     integral_px = int(((plan["w"] + 1).astype(np.int64) * (plan["h"] + 1)).sum())
@@ -169,6 +177,7 @@ def main():
                         f"{args.min_neighbors}), {len(plan)} scales, {windows_per_frame} grid windows/frame",
             "cascade": os.path.basename(args.cascade) + " (synthetic, stock 25-stage/2913-stump profile)",
             "visited_windows_frame0": visited0,
+            "kernel_specialized_stages": spec_stages,
             "frames_per_gpu_per_step": B,
             "frame_content": "1/f noise (sigma 40) + 5 pasted face templates",
             "parallelism": f"frames sharded over {world} GPU(s); RCCL gather of detections only",

@@ -162,6 +162,9 @@ class CascadeClassifier {
   void detectMultiScale(const cv::Mat& image, std::vector<cv::Rect>& objects, double scaleFactor = 1.1, int minNeighbors = 3,
                         int flags = 0, cv::Size minSize = cv::Size(), cv::Size maxSize = cv::Size());
   cv::Size getOriginalWindowSize() const;
+  // Optional, once per loaded cascade: compile its first stages into the cascade kernel (cc_detector_specialize).
+  // Returns the number of stages in effect; 0 if the cascade or the installation does not support it (lastError()).
+  int specialize(int nStages = 7);
   const std::string& lastError() const { return err; }
 
  private:

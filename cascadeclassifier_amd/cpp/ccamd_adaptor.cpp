@@ -401,6 +401,16 @@ cv::Size CascadeClassifier::getOriginalWindowSize() const {
   return cv::Size(info.win_w, info.win_h);
 }
 
+int CascadeClassifier::specialize(int nStages) {
+  if (empty()) return 0;
+  if (!d) check(cc_detector_create(c, device, 1, &d), "CascadeClassifier::specialize");
+  if (cc_detector_specialize(d, nStages) != CC_OK) {
+    err = cc_last_error();
+    return 0;
+  }
+  return cc_detector_specialized_stages(d);
+}
+
 void CascadeClassifier::detectMultiScale(const cv::Mat& image, std::vector<cv::Rect>& objects, double scaleFactor, int minNeighbors,
                                          int /*flags*/, cv::Size minSize, cv::Size maxSize) {
   objects.clear();

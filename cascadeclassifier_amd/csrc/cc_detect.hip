@@ -22,9 +22,16 @@
 #include <memory>
 #include <thread>
 
+#include <dlfcn.h>
+
+#include <map>
+#include <mutex>
+
 #include "cc_internal.h"
 
 namespace ccamd {
+
+#include "build/cc_eval_kernel_src.h"  // kEvalKernelSrc: the text of cc_eval_kernel.inc
 
 #define CC_HIP(expr)                                                                                         \
   do {                                                                                                       \
@@ -33,85 +40,7 @@ namespace ccamd {
                                            __FILE__, __LINE__);                                              \
   } while (0)
 
-// Read-only tables (cascade, scale descriptors, tile list) are written by the host before the launch and never by a
-// kernel: addressing them through the constant address space lets wave-uniform reads become scalar loads (s_load).
-#define CC_CONST __attribute__((address_space(4)))
-template <class T>
-__device__ __forceinline__ const T CC_CONST* as_const_table(const T* p) {
-  return (const T CC_CONST*)p;
-}
-// Copies one table record (a multiple of 4 bytes) out of the constant address space, dword by dword.
-template <class T>
-__device__ __forceinline__ T load_record(const T CC_CONST* p) {
-  static_assert(sizeof(T) % 4 == 0, "table records are dword multiples");
-  T out;
-  const int CC_CONST* w = (const int CC_CONST*)p;
-  int* o = reinterpret_cast<int*>(&out);
-#pragma unroll
-  for (unsigned i = 0; i < sizeof(T) / 4; i++) o[i] = w[i];
-  return out;
-}
-
-constexpr int TILE_X = 64;   // window origins per tile row = one wavefront = one rej0 mask word
-#ifndef CC_TILE_Y
-#define CC_TILE_Y 16  // 16 rows x 512 threads measured best (8x512: +13 %, 32x1024: +28 %, 16x1024: +50 % kernel time)
-#endif
-#ifndef CC_EVAL_THREADS
-#define CC_EVAL_THREADS 512
-#endif
-constexpr int TILE_Y = CC_TILE_Y;   // window origin rows per tile
-constexpr int EVAL_THREADS = CC_EVAL_THREADS;  // wavefronts sharing one LDS tile (more waves per LDS byte = better latency hiding)
-constexpr int EVAL_WAVES = EVAL_THREADS / 64;
-constexpr int WIN_PER_THREAD = TILE_Y / EVAL_WAVES;  // window rows per thread in the dense phase
-
-struct ScaleDev {
-  int w, h;
-  int pitch8, pitchI;
-  long long img_ofs, int_ofs, mask_ofs, win_ofs, h_ofs;  // h_ofs: band-total rows of the integral builder
-  int ystep, nx, ny, nxw, nbands;
-  float scale;
-  int win_w, win_h;
-  int xtab_ofs, ytab_ofs;
-};
-
-// Haar stump in tile coordinates. ofs[j][k] = LDS offset of corner k of rect j relative to the window's tile base.
-struct HaarStumpDev {
-  int ofs[3][4];
-  float w[3];
-  float thr, left, right;
-  int nrect;
-  int pad;
-};
-struct LbpStumpDev {
-  int ofs[16];
-  float left, right;
-  int subset[8];
-  int pad[2];
-};
-
-// Internal tree nodes of cascades deeper than stumps (same corner-offset convention as the stump records);
-// child > 0 = node index inside the tree, child <= 0 = leaf index -child.
-struct HaarNodeDev {
-  int ofs[3][4];
-  float w[3];
-  float thr;
-  int left, right;
-  int nrect;
-  int pad;
-};
-struct LbpNodeDev {
-  int ofs[16];
-  int left, right;
-  int subset[8];
-  int pad[2];
-};
-
-struct CandRaw {
-  int frame, scale, gx, gy;
-};
-struct CandOut {
-  int frame, scale, gx, gy, x, y, w, h;
-};
+#include "cc_eval_kernel.inc"
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -361,528 +290,6 @@ __global__ __launch_bounds__(256) void k_stream_dwords(const uint32_t* __restric
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) acc += p[i];
   if (acc == 0x9e3779b9u) atomicAdd(out, acc);  // keeps the loads alive; practically never taken
   atomicAdd(out + 1 + (threadIdx.x & 15), acc);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4: cascade evaluation. Block = 512 threads = 8 wavefronts = one tile of 64 x 16 window origins of one scale.
-// The tile of the `sum` integral the windows touch is staged once into LDS (for STEP 2 with even and odd columns
-// in separate planes, so that a wavefront's stride-2 corner reads are bank-conflict free); every rectangle corner
-// is then an LDS read. The cascade's early exit is handled by COMPACTION instead of divergence:
-//   phase D (dense)  : lane = window column, 2 window rows per thread: variance test + stage 0 for all 1024 windows;
-//                      wave ballots give the stage-0 rejection mask words; survivors are appended to an LDS queue
-//                      (wave ballot + one LDS atomic per wave);
-//   phase T (thread) : stage by stage, one thread per queued window (full wavefronts), survivors re-queued into the
-//                      other LDS queue buffer;
-//   phase W (wave)   : once fewer than `wave_below` windows are left in the block, one wavefront per window: the 64
-//                      lanes split the stage's stumps and reduce their votes. Only used when the stage sums of the
-//                      cascade are provably order-independent (exact in double, checked on the host at load time),
-//                      so the reduction is bit-identical to the sequential CPU accumulation.
-// ------------------------------------------------------------------------------------------------
-template <int STEP>
-struct TileGeom {
-  int cols, rows, plane, row_stride;
-  __host__ __device__ TileGeom(int W0, int H0) {
-    cols = (TILE_X - 1) * STEP + W0 + 1;
-    rows = (TILE_Y - 1) * STEP + H0 + 1;
-    // padded so that the 8- / 16-byte LDS stores of stage_tile stay aligned and inside the row
-    plane = STEP == 2 ? (((cols + 3) / 4 * 4) / 2 + 1) / 2 * 2 : 0;
-    row_stride = STEP == 2 ? 2 * plane : (cols + 3) / 4 * 4;
-  }
-  // LDS offset of integral entry (r, c) of the tile
-  __host__ __device__ int at(int r, int c) const {
-    return STEP == 2 ? r * row_stride + (c & 1) * plane + (c >> 1) : r * row_stride + c;
-  }
-  __host__ __device__ int words() const { return rows * row_stride; }
-};
-
-constexpr int TILE_WINDOWS = TILE_X * TILE_Y;  // 1024
-constexpr int MAX_STAGES = 64;                 // per-stage queue counters live in LDS
-constexpr int PART_DOUBLES = (EVAL_WAVES - 1) * 64;  // partial stage sums of the stump-split phase: (slices-1) x windows
-__host__ __device__ inline int tile_words_padded(int tile_words) { return (tile_words + 3) & ~3; }  // 16-byte multiple
-// LDS bytes per block: integral tile(s) + partial sums + vnf[1024] + 2 queues of u16[1024] + counters
-__host__ __device__ inline size_t eval_lds_bytes(int tile_words, bool tilted) {
-  return (size_t)tile_words_padded(tile_words) * 4 * (tilted ? 2 : 1) + PART_DOUBLES * 8 + TILE_WINDOWS * 4 + 2 * TILE_WINDOWS * 2 +
-         MAX_STAGES * 4;
-}
-
-// Stages the tile of the integral into LDS: one wavefront per tile row, lanes = groups of 4 consecutive entries
-// (16-byte global loads; tile origins are multiples of 64 entries and row pitches multiples of 4, so they are aligned).
-// STEP 2 splits each group into its even and odd columns (two 8-byte LDS stores into the two planes).
-template <int STEP>
-__device__ __forceinline__ void stage_tile(int32_t* lds, const TileGeom<STEP>& G, const int32_t* __restrict__ sum,
-                                           const ScaleDev& S, int x0, int y0) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int quads = (G.cols + 3) >> 2;
-  for (int r = wave; r < G.rows; r += EVAL_WAVES) {
-    const int gr = y0 + r;
-    const int32_t* src = sum + (size_t)gr * S.pitchI;
-    for (int qd = lane; qd < quads; qd += 64) {
-      const int c = qd * 4, gc = x0 + c;
-      int4 v = make_int4(0, 0, 0, 0);
-      if (gr <= S.h) {
-        if (gc + 3 < S.pitchI)
-          v = *reinterpret_cast<const int4*>(src + gc);
-        else {
-          if (gc < S.pitchI) v.x = src[gc];
-          if (gc + 1 < S.pitchI) v.y = src[gc + 1];
-          if (gc + 2 < S.pitchI) v.z = src[gc + 2];
-        }
-        if (gc > S.w) v.x = 0;  // entries right of the integral's last column read as 0
-        if (gc + 1 > S.w) v.y = 0;
-        if (gc + 2 > S.w) v.z = 0;
-        if (gc + 3 > S.w) v.w = 0;
-      }
-      if (STEP == 2) {  // c is a multiple of 4: even columns c, c+2 -> plane 0 at c/2; odd columns c+1, c+3 -> plane 1
-        int32_t* row = lds + r * G.row_stride + (c >> 1);
-        *reinterpret_cast<int2*>(row) = make_int2(v.x, v.z);
-        *reinterpret_cast<int2*>(row + G.plane) = make_int2(v.y, v.w);
-      } else {
-        *reinterpret_cast<int4*>(lds + r * G.row_stride + c) = v;
-      }
-    }
-  }
-}
-
-struct EvalArgs {
-  const int32_t* integ;
-  size_t int_frame_elems;
-  int nchan;
-  int tilt_chan;      // channel of the tilted integral, -1 if the cascade has no tilted feature
-  const ScaleDev* sd;
-  const int4* tiles;  // {scale, tx, ty, 0}
-  int W0, H0;
-  int nstages;
-  const int* stage_first;  // first stump of each stage
-  const int* stage_ntrees;
-  const float* stage_thr;
-  const void* stumps1;  // stump tables in STEP-1 / STEP-2 tile coordinates
-  const void* stumps2;
-  const void* wstumps1;  // Haar wave phase: per-stage reordered copies (NULL = use stumps1/2)
-  const void* wstumps2;
-  int trees;            // cascade has trees deeper than stumps: node tables below, no stump tables
-  const void* nodes1;
-  const void* nodes2;
-  const int* tree_root;   // first node of each weak classifier
-  const int* tree_leaf0;  // first leaf value of each weak classifier
-  const float* leaves;
-  int wave_below;       // switch to one wavefront per window when fewer windows than this are queued (0 = never)
-  int early_skip;       // drop windows the scan loop provably never visits right after stage 0
-  int split_stumps;     // stage sums are exact (order-independent): wavefronts may split a stage's stumps
-  int stop_after;       // timing experiments only: drop every window still alive after this stage (-1 = off)
-  unsigned long long* masks;
-  size_t mask_frame_words;
-  CandRaw* cands;
-  int* cand_count;
-  int cand_cap;
-  int32_t* dbg_codes;  // optional, frame 0 only
-  double* dbg_sums;
-};
-
-// ---- one weak classifier on one window; `b` = LDS address of the window's tile base ----------------------------
-__device__ __forceinline__ double stump_vote(const int32_t* b, const HaarStumpDev& sp, float vnf) {
-  const int r0 = b[sp.ofs[0][0]] - b[sp.ofs[0][1]] - b[sp.ofs[0][2]] + b[sp.ofs[0][3]];
-  const int r1 = b[sp.ofs[1][0]] - b[sp.ofs[1][1]] - b[sp.ofs[1][2]] + b[sp.ofs[1][3]];
-  float v = sp.w[0] * (float)r0 + sp.w[1] * (float)r1;
-  if (sp.nrect == 3) {
-    const int r2 = b[sp.ofs[2][0]] - b[sp.ofs[2][1]] - b[sp.ofs[2][2]] + b[sp.ofs[2][3]];
-    v += sp.w[2] * (float)r2;
-  }
-  v *= vnf;
-  return (double)(v < sp.thr ? sp.left : sp.right);
-}
-__device__ __forceinline__ double stump_vote(const int32_t* b, const HaarStumpDev CC_CONST* spp, float vnf) {
-  return stump_vote(b, load_record(spp), vnf);
-}
-
-__device__ __forceinline__ double stump_vote(const int32_t* b, const LbpStumpDev CC_CONST* sp, float) {
-  int p[16];
-#pragma unroll
-  for (int j = 0; j < 16; j++) p[j] = b[sp->ofs[j]];
-  const int c = p[5] - p[6] - p[9] + p[10];
-  const int lbp = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
-                  (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
-                  (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
-                  (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
-  const int word = sp->subset[lbp >> 5];  // data-dependent word: read it from the table, not from a register copy
-  return (double)((word & (1 << (lbp & 31))) ? sp->left : sp->right);
-}
-
-// One weak classifier that is a tree: walk from the root; each lane follows its own path (predictOrdered /
-// predictCategorical). The loader guarantees child indices increase, so the walk ends.
-__device__ __forceinline__ double tree_vote(const int32_t* b, const HaarNodeDev* __restrict__ nodes, int root, int leaf0,
-                                            const float* __restrict__ leaves, float vnf) {
-  int idx = 0;
-  do {
-    const HaarNodeDev* n = nodes + root + idx;
-    const int r0 = b[n->ofs[0][0]] - b[n->ofs[0][1]] - b[n->ofs[0][2]] + b[n->ofs[0][3]];
-    const int r1 = b[n->ofs[1][0]] - b[n->ofs[1][1]] - b[n->ofs[1][2]] + b[n->ofs[1][3]];
-    float v = n->w[0] * (float)r0 + n->w[1] * (float)r1;
-    if (n->nrect == 3) v += n->w[2] * (float)(b[n->ofs[2][0]] - b[n->ofs[2][1]] - b[n->ofs[2][2]] + b[n->ofs[2][3]]);
-    v *= vnf;
-    idx = v < n->thr ? n->left : n->right;
-  } while (idx > 0);
-  return (double)leaves[leaf0 - idx];
-}
-__device__ __forceinline__ double tree_vote(const int32_t* b, const LbpNodeDev* __restrict__ nodes, int root, int leaf0,
-                                            const float* __restrict__ leaves, float) {
-  int idx = 0;
-  do {
-    const LbpNodeDev* n = nodes + root + idx;
-    int p[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) p[j] = b[n->ofs[j]];
-    const int c = p[5] - p[6] - p[9] + p[10];
-    const int lbp = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
-                    (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
-                    (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
-                    (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
-    idx = (n->subset[lbp >> 5] & (1 << (lbp & 31))) ? n->left : n->right;
-  } while (idx > 0);
-  return (double)leaves[leaf0 - idx];
-}
-
-// Sum of `v` over the 64 lanes, returned wave-uniform (in scalar registers). Cross-lane moves are DPP modifiers
-// (quad permutes, row mirrors, row broadcasts), not LDS permutes: ~6 short steps. The order of the additions differs
-// from a sequential sum, so callers use it only where the sum is exact (order-independent).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const unsigned long long u = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xF, false);
-  return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ double wave_sum_f64(double v) {
-  v += dpp_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-  v += dpp_f64<0x141, 0xF>(v);  // row_half_mirror
-  v += dpp_f64<0x140, 0xF>(v);  // row_mirror: every lane now holds the total of its row of 16
-  v += dpp_f64<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3 (masked rows add 0)
-  v += dpp_f64<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the wave total
-  const unsigned long long u = __double_as_longlong(v);
-  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, 63);
-  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
-  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
-template <int STEP, bool HAAR, bool TREES>
-__device__ __forceinline__ void eval_tile(const EvalArgs& A, int32_t* lds, const int4 T, const ScaleDev& S) {
-  using Stump = typename std::conditional<HAAR, HaarStumpDev, LbpStumpDev>::type;
-  using Node = typename std::conditional<HAAR, HaarNodeDev, LbpNodeDev>::type;
-  const Node* __restrict__ nodes = reinterpret_cast<const Node*>(STEP == 2 ? A.nodes2 : A.nodes1);
-  const TileGeom<STEP> G(A.W0, A.H0);
-  double* s_part = reinterpret_cast<double*>(lds + tile_words_padded(G.words()) * ((HAAR && A.tilt_chan >= 0) ? 2 : 1));
-  float* s_vnf = reinterpret_cast<float*>(s_part + PART_DOUBLES);
-  unsigned short* s_q = reinterpret_cast<unsigned short*>(s_vnf + TILE_WINDOWS);  // two buffers of TILE_WINDOWS
-  int* s_cnt = reinterpret_cast<int*>(s_q + 2 * TILE_WINDOWS);                   // [stage] = windows that reached it
-  const int frame = blockIdx.y;
-  const int32_t* sum = A.integ + ((size_t)frame * A.nchan + 0) * A.int_frame_elems + S.int_ofs;
-  // the wave index is the same in all 64 lanes; say so, or every loop bounded by it is compiled as divergent
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gx0 = T.y * TILE_X, gy0 = T.z * TILE_Y;
-  const Stump CC_CONST* stumps = as_const_table(reinterpret_cast<const Stump*>(STEP == 2 ? A.stumps2 : A.stumps1));
-  const int CC_CONST* stage_first = as_const_table(A.stage_first);
-  const int CC_CONST* stage_ntrees = as_const_table(A.stage_ntrees);
-  const float CC_CONST* stage_thr = as_const_table(A.stage_thr);
-  const bool dbg = A.dbg_codes != nullptr && frame == 0;
-
-  // The squared-sum integral is needed at 4 corners per window only: read them from global memory, and issue those
-  // loads before the tile is staged so that their latency hides under the staging.
-  unsigned valsq_pre[WIN_PER_THREAD];
-#pragma unroll
-  for (int k = 0; k < WIN_PER_THREAD; k++) {
-    valsq_pre[k] = 0;
-    if (HAAR) {
-      const int gx = gx0 + lane, gy = gy0 + wave * WIN_PER_THREAD + k;
-      if (gx < S.nx && gy < S.ny) {
-        const unsigned* sq = reinterpret_cast<const unsigned*>(A.integ + ((size_t)frame * A.nchan + 1) * A.int_frame_elems + S.int_ofs);
-        const int nrx = A.W0 - 2, nry = A.H0 - 2;
-        const size_t q0 = (size_t)(gy * STEP + 1) * S.pitchI + (gx * STEP + 1);
-        valsq_pre[k] = sq[q0] - sq[q0 + nrx] - sq[q0 + (size_t)nry * S.pitchI] + sq[q0 + (size_t)nry * S.pitchI + nrx];
-      }
-    }
-  }
-  stage_tile<STEP>(lds, G, sum, S, gx0 * STEP, gy0 * STEP);
-  if (HAAR && A.tilt_chan >= 0)  // second tile right behind the first: tilted stumps simply carry offsets shifted by it
-    stage_tile<STEP>(lds + tile_words_padded(G.words()), G,
-                     A.integ + ((size_t)frame * A.nchan + A.tilt_chan) * A.int_frame_elems + S.int_ofs, S, gx0 * STEP, gy0 * STEP);
-  if (threadIdx.x < MAX_STAGES) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-
-  if (A.stop_after == -2) return;  // timing experiments: tile staging only
-  auto window_base = [&](int id) { return ((id >> 6) * STEP) * G.row_stride + (id & 63); };
-  auto report = [&](int id, int code, double last) {  // parity instrumentation
-    const size_t o = (size_t)S.win_ofs + (size_t)(gy0 + (id >> 6)) * S.nx + (gx0 + (id & 63));
-    A.dbg_codes[o] = code;
-    if (A.dbg_sums) A.dbg_sums[o] = last;
-  };
-  auto emit_candidate = [&](int id) {
-    const int slot = atomicAdd(A.cand_count, 1);
-    if (slot < A.cand_cap) A.cands[slot] = CandRaw{frame, T.x, gx0 + (id & 63), gy0 + (id >> 6)};
-  };
-  // appends the calling lanes with `pass` to the queue of stage `st` (whole wavefront must call)
-  auto enqueue = [&](bool pass, int id, int st) {
-    const unsigned long long m = __ballot(pass);
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(&s_cnt[st], __popcll(m));
-    base = __shfl(base, 0);
-    if (pass) s_q[(st & 1) * TILE_WINDOWS + base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)id;
-  };
-
-  // ---------------- phase D: variance test + stage 0, 4 window rows per thread --------------------------------
-  {
-    int base[WIN_PER_THREAD];
-    float vnf[WIN_PER_THREAD];
-    bool alive[WIN_PER_THREAD];
-    const int gx = gx0 + lane;
-#pragma unroll
-    for (int k = 0; k < WIN_PER_THREAD; k++) {
-      const int ly = wave * WIN_PER_THREAD + k;
-      const int gy = gy0 + ly;
-      base[k] = (ly * STEP) * G.row_stride + lane;
-      vnf[k] = 1.f;
-      alive[k] = gx < S.nx && gy < S.ny;
-      if (HAAR) {
-        const bool in_grid = alive[k];
-        alive[k] = false;
-        if (in_grid) {
-          const int nrx = A.W0 - 2, nry = A.H0 - 2;
-          const double area = (double)(nrx * nry);
-          const int32_t* b = lds + base[k];
-          const int valsum = b[G.at(1, 1)] - b[G.at(1, 1 + nrx)] - b[G.at(1 + nry, 1)] + b[G.at(1 + nry, 1 + nrx)];
-          const unsigned valsq = valsq_pre[k];
-          double nf = area * (double)valsq - (double)valsum * (double)valsum;
-          if (nf > 0.) {
-            nf = sqrt(nf);
-            vnf[k] = (float)(1. / nf);
-            alive[k] = area * (double)vnf[k] < 1e-1;
-          }
-          if (dbg && !alive[k]) report(ly * 64 + lane, -1, 0.0);
-        }
-      }
-    }
-    if (A.stop_after == -3) {  // timing experiments: staging + variance test only
-      float sink = 0;
-#pragma unroll
-      for (int k = 0; k < WIN_PER_THREAD; k++) sink += alive[k] ? vnf[k] : 0.f;
-      if (sink == 12345.f) s_vnf[0] = sink;
-      return;
-    }
-    bool any_mine = false;
-    double acc[WIN_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < WIN_PER_THREAD; k++) {
-      any_mine |= alive[k];
-      acc[k] = 0.;
-    }
-    if (__any(any_mine)) {
-      const int nt = stage_ntrees[0];
-      if constexpr (TREES) {
-        for (int i = 0; i < nt; i++) {
-          const int root = as_const_table(A.tree_root)[i], leaf0 = as_const_table(A.tree_leaf0)[i];
-#pragma unroll
-          for (int k = 0; k < WIN_PER_THREAD; k++)
-            if (alive[k]) acc[k] += tree_vote(lds + base[k], nodes, root, leaf0, A.leaves, vnf[k]);
-        }
-      } else if constexpr (HAAR) {
-        // software pipeline: the next stump record is fetched (scalar loads) while this one is evaluated
-        Stump cur = load_record(stumps);
-        for (int i = 0; i < nt; i++) {
-          const Stump nxt = load_record(stumps + min(i + 1, nt - 1));
-#pragma unroll
-          for (int k = 0; k < WIN_PER_THREAD; k++) acc[k] += stump_vote(lds + base[k], cur, vnf[k]);
-          cur = nxt;
-        }
-      } else {
-        for (int i = 0; i < nt; i++) {
-#pragma unroll
-          for (int k = 0; k < WIN_PER_THREAD; k++) acc[k] += stump_vote(lds + base[k], stumps + i, vnf[k]);
-        }
-      }
-    }
-    const double thr = (double)stage_thr[0];
-#pragma unroll
-    for (int k = 0; k < WIN_PER_THREAD; k++) {
-      const int ly = wave * WIN_PER_THREAD + k;
-      const int gy = gy0 + ly;
-      const int id = ly * 64 + lane;
-      bool pass = alive[k] && !(acc[k] < thr);
-      const bool rej0 = alive[k] && !pass;
-      const unsigned long long m = __ballot(rej0);
-      if (lane == 0 && gy < S.ny) A.masks[(size_t)frame * A.mask_frame_words + S.mask_ofs + (size_t)gy * S.nxw + T.y] = m;
-      if (dbg && rej0) report(id, 0, acc[k]);
-      // Stage-0 skip rule, applied early: the scan loop never visits a window whose run of consecutive stage-0
-      // rejections immediately to its left has odd length (k_filter_candidates), so such a window can stop here instead
-      // of walking the later stages for nothing. The run is read off the row's ballot mask; when it reaches the left edge
-      // of this tile its length is only known for the first tile of a row, otherwise the window is kept (the final
-      // filter decides). The parity instrumentation evaluates every window, so it is skipped there.
-      if (!dbg && A.early_skip) {
-        const unsigned long long lower = (1ull << lane) - 1ull;
-        const unsigned long long zeros_below = ~m & lower;  // lower lanes that were NOT rejected at stage 0
-        int run;
-        bool known;
-        if (zeros_below) {
-          run = lane - 1 - (63 - __clzll((long long)zeros_below));
-          known = true;
-        } else {
-          run = lane;
-          known = T.y == 0;
-        }
-        if (known && (run & 1)) pass = false;
-      }
-      if (A.nstages == 1) {
-        if (pass) {
-          emit_candidate(id);
-          if (dbg) report(id, 1, acc[k]);
-        }
-      } else {
-        if (pass) s_vnf[id] = vnf[k];
-        enqueue(pass, id, 1);
-      }
-    }
-  }
-
-  // ---------------- phase T: one thread per queued window, stage by stage -------------------------------------
-  // With fewer than 4*64 windows queued and order-independent (exact) stage sums, the 8 wavefronts also SPLIT THE
-  // STUMPS of the stage (slices j = slice, slice+ns, ...): the partial sums meet in LDS and slice 0 finishes the
-  // window. This keeps all wavefronts busy through the long late stages instead of leaving one wave to walk them.
-  int st = 1;
-  int n = 0;
-  for (; st < A.nstages; st++) {
-    if (A.stop_after >= 0 && st > A.stop_after) return;
-    __syncthreads();  // queue of stage st complete; previous readers of the buffer it overwrites are done
-    n = s_cnt[st];
-    if (n == 0 || n < A.wave_below) break;
-    const unsigned short* q = s_q + (st & 1) * TILE_WINDOWS;
-    const int first = stage_first[st], nt = stage_ntrees[st];
-    const double thr = (double)stage_thr[st];
-    const bool last_stage = st == A.nstages - 1;
-    const int groups = (n + 63) >> 6;  // wavefronts needed to give every window a lane
-    int ns = 1;                        // stump slices
-    if (A.split_stumps)
-      while (ns * 2 * groups <= EVAL_WAVES) ns *= 2;  // largest power of two with ns * groups <= wavefronts
-    auto finish = [&](bool valid, int id, double acc) {  // whole wavefront calls
-      const bool pass = valid && !(acc < thr);
-      if (dbg && valid && !pass) report(id, -st, acc);
-      if (last_stage) {
-        if (pass) {
-          emit_candidate(id);
-          if (dbg) report(id, 1, acc);
-        }
-      } else
-        enqueue(pass, id, st + 1);
-    };
-    if (ns == 1) {
-      for (int i0 = wave * 64; i0 < n; i0 += EVAL_THREADS) {  // wave-uniform trip count
-        const int i = i0 + lane;
-        const bool valid = i < n;
-        const int id = valid ? q[i] : 0;
-        const int32_t* b = lds + window_base(id);
-        const float vnf = HAAR ? s_vnf[id] : 1.f;
-        double acc = 0.;
-        if constexpr (TREES) {
-          for (int j = 0; j < nt; j++) {
-            const int root = as_const_table(A.tree_root)[first + j], leaf0 = as_const_table(A.tree_leaf0)[first + j];
-            if (valid) acc += tree_vote(b, nodes, root, leaf0, A.leaves, vnf);
-          }
-        } else if constexpr (HAAR) {
-          Stump cur = load_record(stumps + first);
-          for (int j = 0; j < nt; j++) {
-            const Stump nxt = load_record(stumps + first + min(j + 1, nt - 1));
-            acc += stump_vote(b, cur, vnf);
-            cur = nxt;
-          }
-        } else {
-          for (int j = 0; j < nt; j++) acc += stump_vote(b, stumps + first + j, vnf);
-        }
-        finish(valid, id, acc);
-      }
-    } else {
-      const int slice = wave % ns, grp = wave / ns;  // EVAL_WAVES / ns groups >= `groups`
-      const int i = grp * 64 + lane;
-      const bool valid = i < n;
-      const int id = valid ? q[i] : 0;
-      double acc = 0.;
-      if (grp < groups) {
-        const int32_t* b = lds + window_base(id);
-        const float vnf = HAAR ? s_vnf[id] : 1.f;
-        if constexpr (HAAR) {
-          if (slice < nt) {
-            Stump cur = load_record(stumps + first + slice);
-            for (int j = slice; j < nt; j += ns) {
-              const Stump nxt = load_record(stumps + first + min(j + ns, nt - 1));
-              acc += stump_vote(b, cur, vnf);
-              cur = nxt;
-            }
-          }
-        } else {
-          for (int j = slice; j < nt; j += ns) acc += stump_vote(b, stumps + first + j, vnf);
-        }
-        if (slice) s_part[(slice - 1) * (EVAL_THREADS / ns) + i] = acc;  // <= (EVAL_WAVES - 1) * 64 entries for every ns
-      }
-      __syncthreads();  // partial sums visible
-      if (grp < groups && slice == 0) {
-        for (int k = 1; k < ns; k++) acc += s_part[(k - 1) * (EVAL_THREADS / ns) + i];
-        finish(valid, id, acc);
-      }
-    }
-  }
-  if (st >= A.nstages || n == 0) return;
-
-  // ---------------- phase W: one wavefront per window, lanes split the stumps ---------------------------------
-  {
-    const unsigned short* q = s_q + (st & 1) * TILE_WINDOWS;
-    const Stump CC_CONST* wstumps = as_const_table(reinterpret_cast<const Stump*>(STEP == 2 ? A.wstumps2 : A.wstumps1));
-    for (int i = wave; i < n; i += EVAL_WAVES) {
-      const int id = q[i];
-      const int32_t* b = lds + window_base(id);
-      const float vnf = HAAR ? s_vnf[id] : 1.f;
-      int s2 = st;
-      double total = 0.;
-      for (; s2 < A.nstages; s2++) {
-        if (A.stop_after >= 0 && s2 > A.stop_after) break;
-        const int first = stage_first[s2], nt = stage_ntrees[s2];
-        double part = 0.;
-        for (int j = lane; j < nt; j += 64) part += stump_vote(b, wstumps + first + j, vnf);
-        total = wave_sum_f64(part);
-        if (total < (double)stage_thr[s2]) break;
-      }
-      if (lane == 0) {
-        if (s2 == A.nstages) emit_candidate(id);
-        if (dbg) report(id, s2 == A.nstages ? 1 : -s2, total);
-      }
-    }
-  }
-}
-
-// One launch covers every scale: the tile's scale decides (block-uniformly) which layout it uses.
-__global__ __launch_bounds__(EVAL_THREADS) void k_eval_haar(EvalArgs A) {
-  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  const int4 T = load_record(as_const_table(A.tiles) + blockIdx.x);
-  const ScaleDev S = load_record(as_const_table(A.sd) + T.x);
-  if (A.trees) {  // rare: cascades with trees deeper than stumps (thread-per-window phases only)
-    if (S.ystep == 2)
-      eval_tile<2, true, true>(A, lds, T, S);
-    else
-      eval_tile<1, true, true>(A, lds, T, S);
-  } else if (S.ystep == 2)
-    eval_tile<2, true, false>(A, lds, T, S);
-  else
-    eval_tile<1, true, false>(A, lds, T, S);
-}
-
-__global__ __launch_bounds__(EVAL_THREADS) void k_eval_lbp(EvalArgs A) {
-  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  const int4 T = load_record(as_const_table(A.tiles) + blockIdx.x);
-  const ScaleDev S = load_record(as_const_table(A.sd) + T.x);
-  if (A.trees) {
-    if (S.ystep == 2)
-      eval_tile<2, false, true>(A, lds, T, S);
-    else
-      eval_tile<1, false, true>(A, lds, T, S);
-  } else if (S.ystep == 2)
-    eval_tile<2, false, false>(A, lds, T, S);
-  else
-    eval_tile<1, false, false>(A, lds, T, S);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1160,6 +567,10 @@ struct cc_detector {
   hipEvent_t front_done[2] = {nullptr, nullptr}, eval_done[2] = {nullptr, nullptr}, batch_begin = nullptr;
   bool eval_pending[2] = {false, false};
   int overlap_front = 1;
+  // run-time specialised cascade kernel (cc_detector_specialize); null = table-driven kernel
+  hipModule_t spec_mod = nullptr;
+  hipFunction_t spec_fn = nullptr;
+  int spec_stages = 0;
   DevBuf<unsigned long long> d_masks;
   DevBuf<CandRaw> d_cands;
   // Results of a pass are double-buffered so that the host can fetch and group pass i while the device runs pass i+1.
@@ -1185,6 +596,7 @@ struct cc_detector {
     if (own_stream) (void)hipStreamDestroy(own_stream);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (front_stream) (void)hipStreamDestroy(front_stream);
+    if (spec_mod) (void)hipModuleUnload(spec_mod);
     for (hipEvent_t e : {pass_done[0], pass_done[1], front_done[0], front_done[1], eval_done[0], eval_done[1], batch_begin})
       if (e) (void)hipEventDestroy(e);
     if (h_counts) (void)hipHostFree(h_counts);
@@ -1286,6 +698,59 @@ static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) 
     d.left = m.stump_left[i];
     d.right = m.stump_right[i];
   }
+}
+
+// Source text of spec_stage<1|2> and spec_stage_part<1|2> for the first n_stages stages: every stump becomes
+// straight-line code whose LDS offsets, weights, threshold and leaf values are literals (hex floats, exact). The
+// expression is the one of stump_vote(), term by term, so results are bit-identical to the table-driven path.
+static std::string spec_stage_source(const Cascade& m, int n_stages) {
+  std::vector<HaarStumpDev> t[2];
+  build_haar_stumps<1>(m, t[0]);
+  build_haar_stumps<2>(m, t[1]);
+  n_stages = std::min<int>(n_stages, (int)m.stage_ntrees.size());
+  std::string o;
+  char buf[512];
+  auto hexf = [&](float v) {
+    snprintf(buf, sizeof(buf), "%af", (double)v);
+    return std::string(buf);
+  };
+  auto stump = [&](const HaarStumpDev& d) {
+    std::string e = "{ float v = ";
+    for (int j = 0; j < d.nrect; j++) {
+      snprintf(buf, sizeof(buf), "%s%s * (float)(b[%d] - b[%d] - b[%d] + b[%d])", j ? " + " : "", hexf(d.w[j]).c_str(), d.ofs[j][0], d.ofs[j][1],
+               d.ofs[j][2], d.ofs[j][3]);
+      e += buf;
+    }
+    return e + "; v *= vnf; acc += (double)(v < " + hexf(d.thr) + " ? " + hexf(d.left) + " : " + hexf(d.right) + "); }";
+  };
+  for (int part = 0; part < 2; part++)
+    for (int step = 1; step <= 2; step++) {
+      if (part)
+        snprintf(buf, sizeof(buf), "template <>\n__device__ __forceinline__ double spec_stage_part<%d>(int st, int slice, int nsm1, const int32_t* b, float vnf) {\n", step);
+      else
+        snprintf(buf, sizeof(buf), "template <>\n__device__ __forceinline__ double spec_stage<%d>(int st, const int32_t* b, float vnf) {\n", step);
+      o += buf;
+      o += "  double acc = 0.;\n  switch (st) {\n";
+      for (int s = 0; s < n_stages; s++) {
+        snprintf(buf, sizeof(buf), "    case %d: {\n", s);
+        o += buf;
+        for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++) {
+          const HaarStumpDev& d = t[step - 1][(size_t)m.stage_first[(size_t)s] + i];
+          if (part) {  // stump i belongs to slice i mod ns (ns a power of two): a wave-uniform scalar test
+            snprintf(buf, sizeof(buf), "      if ((%d & nsm1) == slice) ", i);
+            o += buf;
+            o += stump(d) + "\n";
+          } else {
+            o += "      " + stump(d) + "\n";
+            // keep the scheduler from hoisting every LDS read of the stage to the top (register pressure -> spills)
+            if ((i & 1) == 1) o += "      __builtin_amdgcn_sched_barrier(0);\n";
+          }
+        }
+        o += "    } break;\n";
+      }
+      o += "    default: break;\n  }\n  return acc;\n}\n";
+    }
+  return o;
 }
 
 // Wave phase: lane l of step k evaluates stump (64 k + l) of the stage, so the 32 lanes of a half-wavefront read 32
@@ -1683,7 +1148,10 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.tree_leaf0 = d->d_tree_leaf0.p;
     A.leaves = d->d_leaves.p;
     if (P->n_tiles) {
-      if (haar)
+      if (haar && d->spec_fn && !A.trees) {
+        void* params[] = {&A};
+        CC_HIP(hipModuleLaunchKernel(d->spec_fn, (unsigned)P->n_tiles, (unsigned)nf, 1, EVAL_THREADS, 1, 1, (unsigned)d->lds, st, params, nullptr));
+      } else if (haar)
         hipLaunchKernelGGL(k_eval_haar, dim3(P->n_tiles, nf), dim3(EVAL_THREADS), d->lds, st, A);
       else
         hipLaunchKernelGGL(k_eval_lbp, dim3(P->n_tiles, nf), dim3(EVAL_THREADS), d->lds, st, A);
@@ -1841,6 +1309,89 @@ static void sort_candidates(std::vector<CandOut>& v) {
   });
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Run-time specialisation of the cascade kernel (hiprtc, loaded on demand: the library does not link against it).
+// ------------------------------------------------------------------------------------------------
+struct HipRtcApi {
+  void* lib = nullptr;
+  int (*create)(void**, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+  int (*compile)(void*, int, const char* const*) = nullptr;
+  int (*log_size)(void*, size_t*) = nullptr;
+  int (*log)(void*, char*) = nullptr;
+  int (*code_size)(void*, size_t*) = nullptr;
+  int (*code)(void*, char*) = nullptr;
+  int (*destroy)(void**) = nullptr;
+  bool ok() const { return create && compile && log_size && log && code_size && code && destroy; }
+};
+
+static const HipRtcApi& hiprtc_api() {
+  static HipRtcApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) return;
+    auto sym = [&](const char* n) { return dlsym(api.lib, n); };
+    api.create = reinterpret_cast<decltype(api.create)>(sym("hiprtcCreateProgram"));
+    api.compile = reinterpret_cast<decltype(api.compile)>(sym("hiprtcCompileProgram"));
+    api.log_size = reinterpret_cast<decltype(api.log_size)>(sym("hiprtcGetProgramLogSize"));
+    api.log = reinterpret_cast<decltype(api.log)>(sym("hiprtcGetProgramLog"));
+    api.code_size = reinterpret_cast<decltype(api.code_size)>(sym("hiprtcGetCodeSize"));
+    api.code = reinterpret_cast<decltype(api.code)>(sym("hiprtcGetCode"));
+    api.destroy = reinterpret_cast<decltype(api.destroy)>(sym("hiprtcDestroyProgram"));
+  });
+  return api;
+}
+
+// hiprtc has no <cstdint>: the fixed-width names the kernel source uses
+static const char kSpecPrelude[] =
+    "typedef signed char int8_t;\ntypedef unsigned char uint8_t;\ntypedef short int16_t;\ntypedef unsigned short uint16_t;\n"
+    "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
+
+// Compiles `src` for `arch`; identical (source, options) pairs are served from a per-process cache.
+static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, std::vector<char>& code) {
+  static std::mutex mu;
+  static std::map<std::string, std::vector<char>> cache;
+  const std::string key = arch + "#" + std::to_string(n_stages) + "#" + src;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+      code = it->second;
+      return CC_OK;
+    }
+  }
+  const HipRtcApi& rtc = hiprtc_api();
+  if (!rtc.ok()) return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: libhiprtc is not available (%s)", rtc.lib ? "missing symbols" : "dlopen failed");
+  void* prog = nullptr;
+  if (rtc.create(&prog, src.c_str(), "cc_eval_kernel_spec.hip", 0, nullptr, nullptr) != 0)
+    return set_error(CC_ERR_HIP, "cc_detector_specialize: hiprtcCreateProgram failed");
+  const std::string o_arch = "--offload-arch=" + arch, o_k = "-DCC_SPEC_STAGES=" + std::to_string(n_stages);
+  const std::string o_ty = "-DCC_TILE_Y=" + std::to_string(TILE_Y), o_th = "-DCC_EVAL_THREADS=" + std::to_string(EVAL_THREADS);
+  // same code generation rules as the ahead-of-time build (Makefile): no FMA contraction, no fast-math
+  const char* opts[] = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str()};
+  const int rc = rtc.compile(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+  if (rc != 0) {
+    size_t n = 0;
+    rtc.log_size(prog, &n);
+    std::string log(n + 1, '\0');
+    if (n) rtc.log(prog, &log[0]);
+    rtc.destroy(&prog);
+    return set_error(CC_ERR_HIP, "cc_detector_specialize: hiprtc compilation failed (%d): %.1500s", rc, log.c_str());
+  }
+  size_t n = 0;
+  rtc.code_size(prog, &n);
+  code.resize(n);
+  rtc.code(prog, code.data());
+  rtc.destroy(&prog);
+  std::lock_guard<std::mutex> lk(mu);
+  cache[key] = code;
+  return CC_OK;
+}
+
 }  // namespace ccamd
 
 extern "C" {
@@ -1954,6 +1505,86 @@ void cc_detector_destroy(cc_detector* d) {
 cc_status cc_detector_set_stream(cc_detector* d, void* hip_stream) {
   if (!d) return set_error(CC_ERR_INVALID_ARG, "cc_detector_set_stream: null detector");
   d->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : d->own_stream;
+  return CC_OK;
+}
+
+cc_status cc_detector_specialize(cc_detector* d, int n_stages) {
+  if (!d) return set_error(CC_ERR_INVALID_ARG, "cc_detector_specialize: null detector");
+  cc_status st = ensure_device(d->device);
+  if (st != CC_OK) return st;
+  if (n_stages <= 0) {  // back to the table-driven kernel
+    CC_HIP(hipStreamSynchronize(d->stream));
+    if (d->spec_mod) (void)hipModuleUnload(d->spec_mod);
+    d->spec_mod = nullptr;
+    d->spec_fn = nullptr;
+    d->spec_stages = 0;
+    return CC_OK;
+  }
+  if (d->m.feature_type != CC_FEATURE_HAAR || d->m.max_nodes_per_tree > 1)
+    return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: Haar stump cascades only");
+  // bound the generated code: whole stages while the stump count stays under the budget (instruction cache)
+  int k = 0, stumps = 0;
+  const int budget = 320;
+  while (k < (int)d->m.stage_ntrees.size() && k < n_stages && k < MAX_STAGES && (k == 0 || stumps + d->m.stage_ntrees[(size_t)k] <= budget))
+    stumps += d->m.stage_ntrees[(size_t)k++];
+  std::string src = kSpecPrelude;
+  src += "namespace ccamd {\n";
+  src += kEvalKernelSrc;
+  src += "\n}  // namespace ccamd\n";
+  const std::string marker = "//@@CC_SPEC_FUNCTIONS@@";
+  const size_t pos = src.find(marker);
+  if (pos == std::string::npos) return set_error(CC_ERR_HIP, "cc_detector_specialize: kernel source has no specialisation marker");
+  src.replace(pos, marker.size(), spec_stage_source(d->m, k));
+  hipDeviceProp_t prop;
+  CC_HIP(hipGetDeviceProperties(&prop, d->device));
+  std::string arch = prop.gcnArchName;
+  arch = arch.substr(0, arch.find(':'));
+  std::vector<char> code;
+  st = compile_specialised(src, arch, k, code);
+  if (st != CC_OK) return st;
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  CC_HIP(hipModuleLoadData(&mod, code.data()));
+  if (hipModuleGetFunction(&fn, mod, "k_eval_haar_spec") != hipSuccess) {
+    (void)hipModuleUnload(mod);
+    return set_error(CC_ERR_HIP, "cc_detector_specialize: entry point not found in the compiled module");
+  }
+  if (d->lds > 64 * 1024) {  // same opt-in as the ahead-of-time kernels (cc_detector_create)
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipModuleUnload(mod);
+      return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: %zu bytes of LDS per tile cannot be requested for a run-time module (%s)",
+                       d->lds, hipGetErrorString(e));
+    }
+  }
+  CC_HIP(hipStreamSynchronize(d->stream));
+  if (d->spec_mod) (void)hipModuleUnload(d->spec_mod);
+  d->spec_mod = mod;
+  d->spec_fn = fn;
+  d->spec_stages = k;
+  return CC_OK;
+}
+
+int cc_detector_specialized_stages(const cc_detector* d) { return d ? d->spec_stages : 0; }
+
+cc_status cc_cascade_compile_specialized(const cc_cascade* c, int n_stages, const char* arch, size_t* code_bytes) {
+  if (!c || !arch || !code_bytes) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_compile_specialized: null argument");
+  if (c->m.feature_type != CC_FEATURE_HAAR || c->m.max_nodes_per_tree > 1)
+    return set_error(CC_ERR_UNSUPPORTED, "cc_cascade_compile_specialized: Haar stump cascades only");
+  const int k = std::max(1, std::min<int>({n_stages, (int)c->m.stage_ntrees.size(), MAX_STAGES}));
+  std::string src = kSpecPrelude;
+  src += "namespace ccamd {\n";
+  src += kEvalKernelSrc;
+  src += "\n}  // namespace ccamd\n";
+  const std::string marker = "//@@CC_SPEC_FUNCTIONS@@";
+  const size_t pos = src.find(marker);
+  if (pos == std::string::npos) return set_error(CC_ERR_HIP, "cc_cascade_compile_specialized: kernel source has no specialisation marker");
+  src.replace(pos, marker.size(), spec_stage_source(c->m, k));
+  std::vector<char> code;
+  const cc_status st = compile_specialised(src, arch, k, code);
+  if (st != CC_OK) return st;
+  *code_bytes = code.size();
   return CC_OK;
 }
 

@@ -241,6 +241,15 @@ class CascadeClassifier:
         assert n.value == tot
         return codes[:tot], sums[:tot], vis[:tot]
 
+    def specialize(self, n_stages: int = 4) -> int:
+        """Compile the first n_stages stages of this cascade into the cascade kernel (hiprtc, a few seconds; Haar stump
+        cascades). Results are unchanged; returns the number of stages in effect. n_stages <= 0 switches back."""
+        L.check(L.lib().cc_detector_specialize(self._detector(), int(n_stages)))
+        return self.specialized_stages()
+
+    def specialized_stages(self) -> int:
+        return L.lib().cc_detector_specialized_stages(self._detector())
+
     def set_profiling(self, on: bool):
         L.check(L.lib().cc_detector_set_profiling(self._detector(), 1 if on else 0))
 

@@ -234,6 +234,13 @@ int main(int argc, char** argv) {
     CHECK(objects.empty());
     cascade.detectMultiScale(gray, objects, 1.1, 0);
     std::printf("        ungrouped candidates on the synthetic pattern: %zu\n", objects.size());
+    const int spec = cascade.specialize(3);  // 0 where libhiprtc is missing; results must not change either way
+    std::vector<cv::Rect> again;
+    cascade.detectMultiScale(gray, again, 1.1, 0);
+    CHECK(spec >= 0 && again.size() == objects.size());
+    bool same = again.size() == objects.size();
+    for (size_t i = 0; same && i < again.size(); i++) same = again[i] == objects[i];
+    CHECK(same);
     ccamd::CascadeClassifier missing("/nonexistent.xml");
     CHECK(missing.empty());
     bool threw = false;

@@ -1,0 +1,67 @@
+"""Run-time specialised cascade kernel (cc_detector_specialize, hiprtc): the first stages compiled into straight-line
+code must not change a single bit. Per-window result codes, stage sums, visited flags, candidates and grouped rectangles
+are compared with the CPU oracle AND with the table-driven kernel, for the synthetic stock-profile cascade (all
+specialisation depths incl. the stump-split path), a cascade with tilted features and a non-24x24 window."""
+import numpy as np
+import pytest
+
+import cascadeclassifier_amd as cc
+from oracle import oracle as orc
+from tests import cascade_factory as cf
+from tests.util import frame_natural, frame_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_as_oracle(p, o, img, sf):
+    ref = orc.detect_raw(o, img, sf, nthreads=8, full=True)
+    codes, sums, vis = p.debug_windows(img, sf)
+    assert (codes == ref.codes).all(), f"{(codes != ref.codes).sum()} window results differ"
+    assert (sums == ref.sums).all() and (vis == ref.visited).all()
+    raw = p.detect_raw(img, sf)
+    assert raw.shape == ref.candidates.shape and (raw == ref.candidates).all()
+    a, b = p.detectMultiScale(img, sf, 2), orc.detect_multiscale(o, img, sf, 2, nthreads=8)
+    assert a.shape == b.shape and (a == b).all()
+    return len(raw)
+
+
+@pytest.mark.parametrize("k", [1, 4, 7])
+def test_specialised_stock_profile_cascade(haar_xml, k):
+    o = orc.load_cascade_xml(haar_xml)
+    p = cc.CascadeClassifier(haar_xml)
+    assert p.specialized_stages() == 0
+    got = p.specialize(k)
+    assert 1 <= got <= k and p.specialized_stages() == got
+    img = frame_natural(640, 360, 11)
+    n = _same_as_oracle(p, o, img, 1.1)
+    n += _same_as_oracle(p, o, frame_uniform(300, 200, 12), 1.25)
+    assert n > 0
+    # batch path (several passes, both streams) against the table-driven kernel
+    frames = np.stack([frame_natural(480, 270, 20 + i) for i in range(6)])
+    spec = p.detect_batch(frames, 1.1, 3)
+    p.specialize(0)
+    assert p.specialized_stages() == 0
+    plain = p.detect_batch(frames, 1.1, 3)
+    assert all(a.shape == b.shape and (a == b).all() for a, b in zip(spec, plain))
+
+
+def test_specialised_tilted_and_other_windows(tmp_path):
+    img = frame_natural(320, 240, 3)
+    cal = np.stack([img[y:y + 24, x:x + 24] for y in range(0, 200, 9) for x in range(0, 280, 11)])
+    xml = cf.tilted_stump_cascade(cal)
+    path = str(tmp_path / "t.xml")
+    open(path, "w").write(xml)
+    p = cc.CascadeClassifier(path)
+    assert p.specialize(8) >= 1
+    _same_as_oracle(p, orc.load_cascade_xml(path), frame_natural(333, 127, 6), 1.2)
+
+
+def test_specialise_refuses_what_it_does_not_cover(lbp_xml, tmp_path):
+    with pytest.raises(cc.CascadeError, match="Haar stump cascades only"):
+        cc.CascadeClassifier(lbp_xml).specialize(4)
+    img = frame_natural(320, 240, 3)
+    cal = np.stack([img[y:y + 24, x:x + 24] for y in range(0, 200, 9) for x in range(0, 280, 11)])
+    trees = cc.CascadeClassifier()
+    assert trees.load_from_string(cf.haar_tree_cascade(cal, with_tilted=False))
+    with pytest.raises(cc.CascadeError, match="Haar stump cascades only"):
+        trees.specialize(2)

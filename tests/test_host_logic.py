@@ -156,3 +156,22 @@ def test_product_never_imports_the_oracle(repo_root):
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dp, f), errors="replace").read()
                 assert "oracle" not in text.lower().replace("no cpu fallback", ""), f"{f} mentions the oracle"
+
+
+def test_specialised_kernel_source_compiles_for_gfx950(haar_xml):
+    """cc_detector_specialize's generated source (cascade constants as immediates) through hiprtc, compile only: the CPU-side
+    build check of the run-time path. Skipped where libhiprtc is not installed."""
+    import ctypes as C
+
+    from cascadeclassifier_amd import _lib as L
+    lib = L.lib()
+    c = C.c_void_p()
+    L.check(lib.cc_cascade_load_xml(haar_xml.encode(), C.byref(c)))
+    n = C.c_size_t(0)
+    st = lib.cc_cascade_compile_specialized(c, 2, b"gfx950", C.byref(n))
+    msg = lib.cc_last_error().decode()
+    lib.cc_cascade_destroy(c)
+    if st == L.CC_ERR_UNSUPPORTED and "libhiprtc" in msg:
+        pytest.skip(msg)
+    assert st == L.CC_OK, msg
+    assert n.value > 10000
