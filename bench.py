@@ -144,7 +144,7 @@ def main():
     # windows the scan actually visits (grid windows minus the positions the stage-0 skip rule jumps over), frame 0,
     # outside the timed region (SURVEY.md §8d asks for it next to the grid count)
     visited0 = None
-    if rank == 0 and not args.device_only:
+    if rank == 0 and not args.device_only and not os.environ.get("CCAMD_BENCH_NO_VISITED"):  # (one extra 1-frame launch)
         visited0 = int(clf.debug_windows(frames_host[0], args.scale_factor)[2].sum())
     total_windows = windows_per_frame * B * world * args.steps
     value = total_windows / dt / 1e6
@@ -187,7 +187,7 @@ def main():
         "frames_per_s": round(B * world * args.steps / dt, 2),
         "kernel_ms_per_step": {k: round(tm[k] / args.steps, 4) for k in ("resize_ms", "integral_ms", "eval_ms", "finalize_ms")},
         "roofline": {
-            "kernel": "k_eval_haar" if inf["feature_type"] == 0 else "k_eval_lbp",
+            "kernel": ("k_eval_haar_spec" if spec_stages else "k_eval_haar") if inf["feature_type"] == 0 else "k_eval_lbp",
             "bound": "hbm",
             "achieved": round(ach, 2),
             "peak": HBM_PEAK_GBS,

@@ -1364,6 +1364,12 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
       return CC_OK;
     }
   }
+  if (const char* dump = std::getenv("CCAMD_DUMP_SPEC_SOURCE")) {  // for inspection with hipcc -S
+    if (FILE* f = std::fopen(dump, "w")) {
+      std::fwrite(src.data(), 1, src.size(), f);
+      std::fclose(f);
+    }
+  }
   const HipRtcApi& rtc = hiprtc_api();
   if (!rtc.ok()) return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: libhiprtc is not available (%s)", rtc.lib ? "missing symbols" : "dlopen failed");
   void* prog = nullptr;
