@@ -23,6 +23,8 @@
 #include <thread>
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <map>
 #include <mutex>
@@ -1364,6 +1366,39 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
       return CC_OK;
     }
   }
+  // second level: code objects on disk ($CCAMD_CACHE_DIR, else ~/.cache/cascadeclassifier_amd; CCAMD_CACHE_DIR= disables),
+  // named by a 64-bit FNV-1a hash of architecture, options and source; the file repeats the key length as a check
+  std::string cache_file;
+  {
+    const char* dir = std::getenv("CCAMD_CACHE_DIR");
+    std::string base;
+    if (dir)
+      base = dir;
+    else if (const char* home = std::getenv("HOME"))
+      base = std::string(home) + "/.cache/cascadeclassifier_amd";
+    if (!base.empty()) {
+      unsigned long long h = 1469598103934665603ull;
+      for (unsigned char ch : key) h = (h ^ ch) * 1099511628211ull;
+      char name[64];
+      snprintf(name, sizeof(name), "/spec_%016llx_%zu.hsaco", h, key.size());
+      cache_file = base + name;
+      if (FILE* f = std::fopen(cache_file.c_str(), "rb")) {
+        std::fseek(f, 0, SEEK_END);
+        const long n = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        std::vector<char> buf(n > 0 ? (size_t)n : 0);
+        const bool ok = n > 64 && std::fread(buf.data(), 1, buf.size(), f) == buf.size() && std::memcmp(buf.data(), "\x7f" "ELF", 4) == 0;
+        std::fclose(f);
+        if (ok) {
+          code = buf;
+          std::lock_guard<std::mutex> lk(mu);
+          cache[key] = code;
+          return CC_OK;
+        }
+      }
+      (void)::mkdir(base.c_str(), 0755);  // one level; a missing parent just means no disk cache
+    }
+  }
   if (const char* dump = std::getenv("CCAMD_DUMP_SPEC_SOURCE")) {  // for inspection with hipcc -S
     if (FILE* f = std::fopen(dump, "w")) {
       std::fwrite(src.data(), 1, src.size(), f);
@@ -1393,6 +1428,14 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
   code.resize(n);
   rtc.code(prog, code.data());
   rtc.destroy(&prog);
+  if (!cache_file.empty()) {  // write to a private name, then rename: readers never see a partial file
+    const std::string tmp = cache_file + "." + std::to_string((long long)::getpid()) + ".tmp";
+    if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
+      const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
+      std::fclose(f);
+      if (!ok || std::rename(tmp.c_str(), cache_file.c_str()) != 0) (void)std::remove(tmp.c_str());
+    }
+  }
   std::lock_guard<std::mutex> lk(mu);
   cache[key] = code;
   return CC_OK;

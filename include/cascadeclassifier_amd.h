@@ -178,8 +178,9 @@ CC_API cc_status cc_scale_plan(int win_w, int win_h, int width, int height, cons
 /* Run-time specialisation of the cascade kernel for THIS detector's cascade (Haar stump cascades): the first n_stages
  * stages (whole stages, capped by a code-size budget) are compiled with hiprtc into straight-line code whose LDS offsets,
  * weights, thresholds and leaf values are immediates; later stages stay table-driven. Same arithmetic, identical results;
- * the cascade kernel runs about 13 % faster on the bench cascade. Takes a few seconds (cached per process for identical
- * cascades); libhiprtc is loaded on demand and a missing library is CC_ERR_UNSUPPORTED, in which case the detector keeps
+ * the cascade kernel runs about 17 % faster on the bench cascade. Takes a few seconds the first time; code objects are
+ * cached per process and on disk ($CCAMD_CACHE_DIR, default ~/.cache/cascadeclassifier_amd; set it empty to disable),
+ * keyed by architecture, options and generated source. libhiprtc is loaded on demand and a missing library is CC_ERR_UNSUPPORTED, in which case the detector keeps
  * using the table-driven kernel. n_stages <= 0 switches back. cc_detector_specialized_stages reports the stages in
  * effect (0 = none). cc_cascade_compile_specialized only compiles (no device needed; arch e.g. "gfx950") and returns
  * the code-object size: the build check of the generated source. */

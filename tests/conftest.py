@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # keep the specialised-kernel cache of this test session out of the user's home
+    if "CCAMD_CACHE_DIR" not in os.environ:
+        import tempfile
+        os.environ["CCAMD_CACHE_DIR"] = tempfile.mkdtemp(prefix="ccamd_cache_")
 
 
 @pytest.fixture(scope="session")

@@ -175,3 +175,14 @@ def test_specialised_kernel_source_compiles_for_gfx950(haar_xml):
         pytest.skip(msg)
     assert st == L.CC_OK, msg
     assert n.value > 10000
+    # the code object is now in the per-process cache and on disk ($CCAMD_CACHE_DIR): same size, no recompilation
+    import glob
+    import os
+    import time
+    assert glob.glob(os.path.join(os.environ["CCAMD_CACHE_DIR"], "spec_*.hsaco"))
+    L.check(lib.cc_cascade_load_xml(haar_xml.encode(), C.byref(c)))
+    m = C.c_size_t(0)
+    t0 = time.perf_counter()
+    L.check(lib.cc_cascade_compile_specialized(c, 2, b"gfx950", C.byref(m)))
+    assert m.value == n.value and time.perf_counter() - t0 < 0.5
+    lib.cc_cascade_destroy(c)
