@@ -716,12 +716,49 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
     snprintf(buf, sizeof(buf), "%af", (double)v);
     return std::string(buf);
   };
-  auto stump = [&](const HaarStumpDev& d) {
-    std::string e = "{ float v = ";
+  // One stump as an expression. When every weight is a small integer and sum |w_j| * 255 * area_j < 2^24, every
+  // intermediate of the float expression w0*(float)r0 + w1*(float)r1 [+ w2*(float)r2] is an exactly representable
+  // integer, so the value equals (float) of the same combination computed in int32: corners shared by the rectangles
+  // merge, one conversion instead of three, no float multiplies. Otherwise the float expression is emitted term by term.
+  auto stump = [&](const HaarStumpDev& d, int stump_index) {
+    const int fi = m.stump_feature[(size_t)stump_index];
+    bool int_ok = true;
+    double bound = 0;
     for (int j = 0; j < d.nrect; j++) {
-      snprintf(buf, sizeof(buf), "%s%s * (float)(b[%d] - b[%d] - b[%d] + b[%d])", j ? " + " : "", hexf(d.w[j]).c_str(), d.ofs[j][0], d.ofs[j][1],
-               d.ofs[j][2], d.ofs[j][3]);
-      e += buf;
+      const float w = d.w[j];
+      const int32_t* r = &m.haar_rects[(size_t)fi * 12 + j * 4];
+      if (w != std::nearbyint(w) || std::fabs(w) > 64.f) int_ok = false;
+      bound += std::fabs((double)w) * 255.0 * (double)r[2] * (double)r[3] * (m.haar_tilted[(size_t)fi] ? 2.0 : 1.0);
+    }
+    if (bound >= 16777216.0) int_ok = false;
+    std::string e = "{ float v = ";
+    if (int_ok) {
+      std::map<int, int> coef;  // LDS offset -> integer coefficient
+      static const int sign[4] = {1, -1, -1, 1};
+      for (int j = 0; j < d.nrect; j++)
+        for (int k = 0; k < 4; k++) coef[d.ofs[j][k]] += sign[k] * (int)d.w[j];
+      std::map<int, std::vector<int>> by_coef;  // |coefficient| -> signed offsets (+ofs+1 / -(ofs+1))
+      for (auto& kv : coef)
+        if (kv.second) by_coef[std::abs(kv.second)].push_back(kv.second > 0 ? kv.first + 1 : -(kv.first + 1));
+      std::string t;
+      for (auto& g : by_coef) {
+        std::string grp;
+        for (int so : g.second) {
+          snprintf(buf, sizeof(buf), "%s(unsigned)b[%d]", so > 0 ? (grp.empty() ? "" : " + ") : " - ", std::abs(so) - 1);
+          grp += buf;
+        }
+        if (grp.rfind(" - ", 0) == 0) grp = "0u" + grp;
+        snprintf(buf, sizeof(buf), "%s%du * (%s)", t.empty() ? "" : " + ", g.first, grp.c_str());  // unsigned: wrap-around is defined
+        t += buf;
+      }
+      if (t.empty()) t = "0u";
+      e += "(float)(int)(" + t + ")";
+    } else {
+      for (int j = 0; j < d.nrect; j++) {
+        snprintf(buf, sizeof(buf), "%s%s * (float)(b[%d] - b[%d] - b[%d] + b[%d])", j ? " + " : "", hexf(d.w[j]).c_str(), d.ofs[j][0], d.ofs[j][1],
+                 d.ofs[j][2], d.ofs[j][3]);
+        e += buf;
+      }
     }
     return e + "; v *= vnf; acc += (double)(v < " + hexf(d.thr) + " ? " + hexf(d.left) + " : " + hexf(d.right) + "); }";
   };
@@ -741,9 +778,9 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
           if (part) {  // stump i belongs to slice i mod ns (ns a power of two): a wave-uniform scalar test
             snprintf(buf, sizeof(buf), "      if ((%d & nsm1) == slice) ", i);
             o += buf;
-            o += stump(d) + "\n";
+            o += stump(d, m.stage_first[(size_t)s] + i) + "\n";
           } else {
-            o += "      " + stump(d) + "\n";
+            o += "      " + stump(d, m.stage_first[(size_t)s] + i) + "\n";
             // keep the scheduler from hoisting every LDS read of the stage to the top (register pressure -> spills)
             if ((i & 1) == 1) o += "      __builtin_amdgcn_sched_barrier(0);\n";
           }
