@@ -227,3 +227,49 @@ def test_variables_sharded_over_two_devices_worth_of_ranges():
         got = pick_split(parts)
         assert got["found"] and got["var_idx"] == whole["var_idx"] and got["quality"] == whole["quality"]
         assert got["ord_c"] == whole["ord_c"] and got["split_point"] == whole["split_point"] and (got["subset"] == whole["subset"]).all()
+
+
+def test_gentle_adaboost_rounds_pick_identical_stumps():
+    """Ten rounds of Gentle AdaBoost with stumps (CvCascadeBoost::train -> update_weights, boost.cpp:378-398: weak response
+    f = weighted mean of y in the leaf, w *= exp(-y f), renormalise), the weights evolving from round to round: every
+    round the device search and the oracle choose the same variable, threshold and quality, for Haar and for LBP."""
+    for ftype, mode in ((ev.HAAR, ev.CORE), (ev.LBP, 0)):
+        n = 360
+        e, imgs, labels, ints = _setup(ftype, mode, WIN, n, 31, dup=12)
+        vals_all = _oracle_vals(ftype, mode, WIN, ints, None)
+        y = (labels.astype(np.float64) * 2 - 1)
+        resp = y.astype(np.float32)
+        w = np.full(n, 1.0 / n)
+        chosen = []
+        for rnd in range(10):
+            tot = 0.0
+            s = 0.0
+            for i in range(n):  # calc_node_value of the root, o_cvboostree.cpp:711-722
+                tot += w[i]
+                s += float(resp[i]) * w[i]
+            W = np.concatenate([w, [tot, 0.0]])
+            nv = s * (1.0 / tot)
+            got = e.find_best_split(W, responses=resp, node_value=nv)
+            want = orc.find_best_split(vals_all, W, categorical=ftype == ev.LBP, responses=resp, node_value=nv)
+            assert got["found"] and bool(want["found"]), rnd
+            assert got["var_idx"] == want["var_idx"] and got["quality"] == want["quality"], rnd
+            assert got["ord_c"] == want["ord_c"] and got["split_point"] == want["split_point"] and (got["subset"] == want["subset"]).all(), rnd
+            chosen.append(got["var_idx"])
+            v = e.calc_batch(got["var_idx"], got["var_idx"] + 1)[0]
+            assert (v == vals_all[got["var_idx"]]).all()
+            if ftype == ev.HAAR:
+                left = v <= got["ord_c"]
+            else:
+                code = v.astype(np.int32)
+                left = (got["subset"][code >> 5] >> (code & 31)) & 1 == 1
+            f = np.empty(n)
+            for side in (left, ~left):
+                sw = 0.0
+                sy = 0.0
+                for i in np.nonzero(side)[0]:
+                    sw += w[i]
+                    sy += y[i] * w[i]
+                f[side] = sy * (1.0 / sw) if sw > 0 else 0.0
+            w = w * np.exp(-y * f)
+            w = w * (1.0 / w.sum())
+        assert len(set(chosen)) > 3  # boosting moves on to other variables as the weights change
