@@ -1,0 +1,23 @@
+#!/bin/bash
+# Issue / LDS counters of the cascade kernel (own rocprofv3 pass, kernel trace only). $1 = tag, rest = bench args.
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export CCAMD_BENCH_NO_VISITED=1 CCAMD_NO_FRONT_OVERLAP=1
+out=gpurun_out/pmc_$tag
+mkdir -p $out
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $out -- python3 bench.py --cpu-frames 0 --steps 2 --warmup 1 "$@" > $out/log.txt 2>&1
+python3 - <<PY
+import csv,glob,collections
+f=glob.glob("$out/*/*counter_collection.csv")[0]
+agg=collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,v in agg.items():
+    if "k_eval" in k:
+        m={c:sum(x)/len(x) for c,x in v.items()}
+        print(k, {c:round(x) for c,x in m.items()})
+        if m.get("SQ_LDS_IDX_ACTIVE"):
+            print("  LDS conflict share of LDS-active cycles:", round(m["SQ_LDS_BANK_CONFLICT"]/m["SQ_LDS_IDX_ACTIVE"],3))
+        if m.get("SQ_BUSY_CYCLES"):
+            print("  LDS active / SQ busy:", round(m["SQ_LDS_IDX_ACTIVE"]/m["SQ_BUSY_CYCLES"],3), " VALU active / SQ busy:", round(m["SQ_ACTIVE_INST_VALU"]/m["SQ_BUSY_CYCLES"],3))
+PY
