@@ -1394,7 +1394,14 @@ static const char kSpecPrelude[] =
 static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, std::vector<char>& code) {
   static std::mutex mu;
   static std::map<std::string, std::vector<char>> cache;
-  const std::string key = arch + "#" + std::to_string(n_stages) + "#" + src;
+  const std::string o_arch = "--offload-arch=" + arch, o_k = "-DCC_SPEC_STAGES=" + std::to_string(n_stages);
+  const std::string o_ty = "-DCC_TILE_Y=" + std::to_string(TILE_Y), o_th = "-DCC_EVAL_THREADS=" + std::to_string(EVAL_THREADS);
+  // same code generation rules as the ahead-of-time build (Makefile): no FMA contraction, no fast-math
+  const char* opts[] = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str()};
+  const int n_opts = (int)(sizeof(opts) / sizeof(opts[0]));
+  std::string key;  // everything the code object depends on: options, then the source
+  for (int i = 0; i < n_opts; i++) key += std::string(opts[i]) + " ";
+  key += "#" + src;
   {
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
@@ -1447,11 +1454,7 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
   void* prog = nullptr;
   if (rtc.create(&prog, src.c_str(), "cc_eval_kernel_spec.hip", 0, nullptr, nullptr) != 0)
     return set_error(CC_ERR_HIP, "cc_detector_specialize: hiprtcCreateProgram failed");
-  const std::string o_arch = "--offload-arch=" + arch, o_k = "-DCC_SPEC_STAGES=" + std::to_string(n_stages);
-  const std::string o_ty = "-DCC_TILE_Y=" + std::to_string(TILE_Y), o_th = "-DCC_EVAL_THREADS=" + std::to_string(EVAL_THREADS);
-  // same code generation rules as the ahead-of-time build (Makefile): no FMA contraction, no fast-math
-  const char* opts[] = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str()};
-  const int rc = rtc.compile(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+  const int rc = rtc.compile(prog, n_opts, opts);
   if (rc != 0) {
     size_t n = 0;
     rtc.log_size(prog, &n);
