@@ -529,6 +529,16 @@ struct Plan {
   DevBuf<int> d_resize_first, d_band_first, d_col_first, d_gridrow_first, d_diag_first, d_tcol_first, d_xofs, d_yofs;
   DevBuf<uint16_t> d_xw1, d_yw1;
   DevBuf<int4> d_tiles;
+  // Single-image calls (the detection tool's shape) are launch-bound: ~10 launches, memsets and copies for well under a
+  // millisecond of device work. After a first ordinary call has sized every buffer, the whole pass (H2D copy of the
+  // image, pyramid, integrals, cascade kernel, skip filter, copy-back of the counters) is captured into a hipGraph and
+  // replayed with one launch for as long as the buffers and kernels it recorded stay the same (`graph_key`).
+  bool graph_warm = false;
+  hipGraphExec_t graph_exec = nullptr;
+  std::vector<const void*> graph_key;
+  ~Plan() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+  }
 };
 
 struct TimingEvent {
@@ -579,6 +589,9 @@ struct cc_detector {
   DevBuf<CandOut> d_out[2];
   DevBuf<int> d_counts[2];  // [0] raw count, [1] filtered count
   int* h_counts = nullptr;  // pinned, 2 x 2 ints
+  uint8_t* h_frame = nullptr;  // pinned staging copy of a single host image (graph path)
+  size_t h_frame_bytes = 0;
+  int use_graph = 1;
   hipStream_t copy_stream = nullptr;
   hipEvent_t pass_done[2] = {nullptr, nullptr};
   int cand_cap = 0;
@@ -602,6 +615,7 @@ struct cc_detector {
     for (hipEvent_t e : {pass_done[0], pass_done[1], front_done[0], front_done[1], eval_done[0], eval_done[1], batch_begin})
       if (e) (void)hipEventDestroy(e);
     if (h_counts) (void)hipHostFree(h_counts);
+    if (h_frame) (void)hipHostFree(h_frame);
   }
 };
 
@@ -1104,10 +1118,10 @@ static void launch_integral(hipStream_t st, bool sq, const uint8_t* pyr, size_t 
 // Device pipeline for up to max_batch frames already resident on the device. Leaves the filtered candidate list
 // (d_out[slot], d_counts[slot][1]) on the device; no synchronisation.
 static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes, int nf, size_t row_stride,
-                                 size_t frame_stride, bool debug, int slot) {
+                                 size_t frame_stride, bool debug, int slot, bool single_stream = false) {
   const int ns = (int)P->sd.size();
   hipStream_t st = d->stream;
-  hipStream_t fs = d->overlap_front ? d->front_stream : d->stream;  // pyramid + integrals
+  hipStream_t fs = d->overlap_front && !single_stream ? d->front_stream : d->stream;  // pyramid + integrals
   const bool haar = d->m.feature_type == CC_FEATURE_HAAR;
   const bool tilt = haar && d->m.has_tilted;
   const int nchan = haar ? (tilt ? 3 : 2) : 1;  // sum, sqsum, tilted
@@ -1246,11 +1260,74 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     for (hipEvent_t* e : {&d->front_done[0], &d->front_done[1], &d->eval_done[0], &d->eval_done[1], &d->batch_begin})
       CC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     d->overlap_front = std::getenv("CCAMD_NO_FRONT_OVERLAP") ? 0 : 1;
+    d->use_graph = std::getenv("CCAMD_NO_GRAPH") ? 0 : 1;
   }
   hipStream_t front = d->overlap_front ? d->front_stream : d->stream;
   if (front != d->stream) {  // frames produced by earlier work on the caller's stream must be complete before the pyramid reads them
     CC_HIP(hipEventRecord(d->batch_begin, d->stream));
     CC_HIP(hipStreamWaitEvent(front, d->batch_begin, 0));
+  }
+  if (n_frames == 1 && !on_device && want_results && !debug && !d->profiling && d->use_graph) {
+    // ---- single host image: one pass on one stream, replayed from a hipGraph once the buffers are sized ----
+    const size_t rs = (size_t)align_up(width, 4), fs = rs * (size_t)height;
+    if (d->h_frame_bytes < fs) {
+      if (d->h_frame) (void)hipHostFree(d->h_frame);
+      d->h_frame = nullptr;
+      d->h_frame_bytes = 0;
+      CC_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->h_frame), fs, hipHostMallocDefault));
+      d->h_frame_bytes = fs;
+    }
+    for (int y = 0; y < height; y++) std::memcpy(d->h_frame + (size_t)y * rs, frames + (size_t)y * row_stride, (size_t)width);
+    CC_HIP(d->d_frames.ensure(fs * (size_t)d->max_batch * 2));
+    auto body = [&]() -> cc_status {
+      CC_HIP(hipMemcpyAsync(d->d_frames.p, d->h_frame, fs, hipMemcpyHostToDevice, d->stream));
+      cc_status s2 = run_device_pass(d, P, d->d_frames.p, 1, rs, fs, false, 0, true);
+      if (s2 != CC_OK) return s2;
+      CC_HIP(hipMemcpyAsync(d->h_counts, d->d_counts[0].p, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+      return CC_OK;
+    };
+    auto key_now = [&]() {
+      return std::vector<const void*>{d->d_frames.p, d->h_frame, d->d_pyr.p, d->d_integ[0].p, d->d_hbuf.p, d->d_diag.p, d->d_masks.p, d->d_cands.p,
+                                      d->d_out[0].p, d->d_counts[0].p, d->h_counts, (const void*)d->spec_fn, (const void*)d->stream,
+                                      (const void*)(size_t)d->cand_cap, (const void*)(size_t)d->wave_below, (const void*)(size_t)(d->stop_after + 16)};
+    };
+    if (d->eval_pending[0] || d->eval_pending[1]) {  // a batch call may still be using the buffers on the other stream
+      CC_HIP(hipStreamSynchronize(d->front_stream));
+      d->eval_pending[0] = d->eval_pending[1] = false;
+    }
+    if (P->graph_exec && P->graph_key == key_now()) {
+      CC_HIP(hipGraphLaunch(P->graph_exec, d->stream));
+    } else if (P->graph_warm) {
+      if (P->graph_exec) (void)hipGraphExecDestroy(P->graph_exec);
+      P->graph_exec = nullptr;
+      hipGraph_t graph = nullptr;
+      CC_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal));
+      const cc_status s2 = body();
+      const hipError_t ce = hipStreamEndCapture(d->stream, &graph);
+      if (s2 != CC_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return s2;
+      }
+      CC_HIP(ce);
+      const hipError_t ie = hipGraphInstantiate(&P->graph_exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      CC_HIP(ie);
+      P->graph_key = key_now();
+      CC_HIP(hipGraphLaunch(P->graph_exec, d->stream));
+    } else {
+      stt = body();
+      if (stt != CC_OK) return stt;
+      P->graph_warm = true;  // every buffer now has its size: the next call can be captured
+    }
+    CC_HIP(hipStreamSynchronize(d->stream));
+    const int raw = d->h_counts[0], kept = d->h_counts[1];
+    if (raw <= d->cand_cap) {
+      std::vector<CandOut> got((size_t)kept);
+      if (kept > 0) CC_HIP(hipMemcpy(got.data(), d->d_out[0].p, (size_t)kept * sizeof(CandOut), hipMemcpyDeviceToHost));
+      consume(0, 1, got);
+      return CC_OK;
+    }
+    // candidate list overflow: the ordinary path below grows the lists and redoes the pass
   }
   int pass_frames = d->max_batch;
   if (want_results && n_frames >= 2) {  // only the last pass's host work is exposed: use a few passes, not two halves
