@@ -1256,7 +1256,12 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     CC_HIP(hipEventCreateWithFlags(&d->pass_done[0], hipEventDisableTiming));
     CC_HIP(hipEventCreateWithFlags(&d->pass_done[1], hipEventDisableTiming));
     CC_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->h_counts), 4 * sizeof(int), hipHostMallocDefault));
-    CC_HIP(hipStreamCreateWithFlags(&d->front_stream, hipStreamNonBlocking));
+    {  // the pyramid / integral stream only fills what the cascade kernel leaves idle: lowest priority
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (std::getenv("CCAMD_FRONT_SAME_PRIORITY")) least = greatest;
+      CC_HIP(hipStreamCreateWithPriority(&d->front_stream, hipStreamNonBlocking, least));
+    }
     for (hipEvent_t* e : {&d->front_done[0], &d->front_done[1], &d->eval_done[0], &d->eval_done[1], &d->batch_begin})
       CC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     d->overlap_front = std::getenv("CCAMD_NO_FRONT_OVERLAP") ? 0 : 1;
@@ -1335,6 +1340,12 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     if (const char* e = std::getenv("CCAMD_PIPELINE_PASSES")) passes = std::max(1, std::atoi(e));
     passes = std::min(passes, n_frames);
     pass_frames = std::min(d->max_batch, (n_frames + passes - 1) / passes);
+    // the host work of the LAST pass (copy-back + grouping) is the only part nothing overlaps: give it about half the
+    // frames of the others (32 frames in 4 passes -> 9, 9, 9, 5)
+    if (passes >= 3 && !std::getenv("CCAMD_EVEN_PASSES")) {
+      const int big = std::min(d->max_batch, (2 * n_frames + 2 * passes - 2) / (2 * passes - 1));
+      if (big >= 2 && big * (passes - 1) < n_frames) pass_frames = big;
+    }
   }
   struct Pass {
     int f0, nf, slot;
