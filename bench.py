@@ -98,7 +98,7 @@ def main():
     assert not clf.empty(), getattr(clf, "load_error", "")
     inf = clf.info()
     spec_stages = 0
-    if args.specialize > 0 and inf["feature_type"] == 0 and inf["max_nodes_per_tree"] == 1:
+    if args.specialize > 0 and inf["max_nodes_per_tree"] == 1:
         try:  # load-time work, outside the timed region; without hiprtc the table-driven kernel stays in use
             spec_stages = clf.specialize(args.specialize)
         except cc.CascadeError as e:
@@ -187,7 +187,7 @@ def main():
         "frames_per_s": round(B * world * args.steps / dt, 2),
         "kernel_ms_per_step": {k: round(tm[k] / args.steps, 4) for k in ("resize_ms", "integral_ms", "eval_ms", "finalize_ms")},
         "roofline": {
-            "kernel": ("k_eval_haar_spec" if spec_stages else "k_eval_haar") if inf["feature_type"] == 0 else "k_eval_lbp",
+            "kernel": "k_eval_spec" if spec_stages else ("k_eval_haar" if inf["feature_type"] == 0 else "k_eval_lbp"),
             "bound": "hbm",
             "achieved": round(ach, 2),
             "peak": HBM_PEAK_GBS,

@@ -719,7 +719,12 @@ static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) 
 // Source text of spec_stage<1|2> and spec_stage_part<1|2> for the first n_stages stages: every stump becomes
 // straight-line code whose LDS offsets, weights, threshold and leaf values are literals (hex floats, exact). The
 // expression is the one of stump_vote(), term by term, so results are bit-identical to the table-driven path.
+static std::string spec_stage_source_lbp(const Cascade& m, int n_stages);
+template <int STEP>
+static void build_lbp_stumps(const Cascade& m, std::vector<LbpStumpDev>& out);
+
 static std::string spec_stage_source(const Cascade& m, int n_stages) {
+  if (m.feature_type == CC_FEATURE_LBP) return spec_stage_source_lbp(m, n_stages);
   std::vector<HaarStumpDev> t[2];
   build_haar_stumps<1>(m, t[0]);
   build_haar_stumps<2>(m, t[1]);
@@ -797,6 +802,74 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
             o += "      " + stump(d, m.stage_first[(size_t)s] + i) + "\n";
             // keep the scheduler from hoisting every LDS read of the stage to the top (register pressure -> spills)
             if ((i & 1) == 1) o += "      __builtin_amdgcn_sched_barrier(0);\n";
+          }
+        }
+        o += "    } break;\n";
+      }
+      o += "    default: break;\n  }\n  return acc;\n}\n";
+    }
+  return o;
+}
+
+// LBP variant: the 16 lattice offsets are immediates; the 256-bit subsets stay a (module-resident) table because the word
+// a lane needs depends on its own code. Integer arithmetic throughout, the expression of stump_vote().
+static std::string spec_stage_source_lbp(const Cascade& m, int n_stages) {
+  std::vector<LbpStumpDev> t[2];
+  build_lbp_stumps<1>(m, t[0]);
+  build_lbp_stumps<2>(m, t[1]);
+  n_stages = std::min<int>(n_stages, (int)m.stage_ntrees.size());
+  std::string o;
+  char buf[768];
+  int n_stumps = 0;
+  for (int s = 0; s < n_stages; s++) n_stumps += m.stage_ntrees[(size_t)s];
+  o += "static __device__ const int kSpecSubsets[][8] = {\n";
+  for (int i = 0; i < n_stumps; i++) {
+    const LbpStumpDev& d = t[0][(size_t)i];
+    snprintf(buf, sizeof(buf), "  {%d, %d, %d, %d, %d, %d, %d, %d},\n", d.subset[0], d.subset[1], d.subset[2], d.subset[3], d.subset[4], d.subset[5],
+             d.subset[6], d.subset[7]);
+    o += buf;
+  }
+  o += "};\n";
+  auto hexf = [&](float v) {
+    char b2[64];
+    snprintf(b2, sizeof(b2), "%af", (double)v);
+    return std::string(b2);
+  };
+  auto stump = [&](const LbpStumpDev& d, int index) {
+    const int* p = d.ofs;
+    snprintf(buf, sizeof(buf),
+             "{ const int c = b[%d] - b[%d] - b[%d] + b[%d]; const int lbp = (b[%d] - b[%d] - b[%d] + b[%d] >= c ? 128 : 0) | "
+             "(b[%d] - b[%d] - b[%d] + b[%d] >= c ? 64 : 0) | (b[%d] - b[%d] - b[%d] + b[%d] >= c ? 32 : 0) | "
+             "(b[%d] - b[%d] - b[%d] + b[%d] >= c ? 16 : 0) | (b[%d] - b[%d] - b[%d] + b[%d] >= c ? 8 : 0) | "
+             "(b[%d] - b[%d] - b[%d] + b[%d] >= c ? 4 : 0) | (b[%d] - b[%d] - b[%d] + b[%d] >= c ? 2 : 0) | "
+             "(b[%d] - b[%d] - b[%d] + b[%d] >= c ? 1 : 0); ",
+             p[5], p[6], p[9], p[10], p[0], p[1], p[4], p[5], p[1], p[2], p[5], p[6], p[2], p[3], p[6], p[7], p[6], p[7], p[10], p[11], p[10],
+             p[11], p[14], p[15], p[9], p[10], p[13], p[14], p[8], p[9], p[12], p[13], p[4], p[5], p[8], p[9]);
+    std::string e = buf;
+    snprintf(buf, sizeof(buf), "acc += (double)((kSpecSubsets[%d][lbp >> 5] & (1 << (lbp & 31))) ? %s : %s); }", index, hexf(d.left).c_str(),
+             hexf(d.right).c_str());
+    return e + buf;
+  };
+  for (int part = 0; part < 2; part++)
+    for (int step = 1; step <= 2; step++) {
+      if (part)
+        snprintf(buf, sizeof(buf), "template <>\n__device__ __forceinline__ double spec_stage_part<%d>(int st, int slice, int nsm1, const int32_t* b, float vnf) {\n", step);
+      else
+        snprintf(buf, sizeof(buf), "template <>\n__device__ __forceinline__ double spec_stage<%d>(int st, const int32_t* b, float vnf) {\n", step);
+      o += buf;
+      o += "  double acc = 0.;\n  switch (st) {\n";
+      for (int s = 0; s < n_stages; s++) {
+        snprintf(buf, sizeof(buf), "    case %d: {\n", s);
+        o += buf;
+        for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++) {
+          const int idx = m.stage_first[(size_t)s] + i;
+          const LbpStumpDev& d = t[step - 1][(size_t)idx];
+          if (part) {
+            snprintf(buf, sizeof(buf), "      if ((%d & nsm1) == slice) ", i);
+            o += buf;
+            o += stump(d, idx) + "\n";
+          } else {
+            o += "      " + stump(d, idx) + "\n      __builtin_amdgcn_sched_barrier(0);\n";
           }
         }
         o += "    } break;\n";
@@ -1201,7 +1274,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.tree_leaf0 = d->d_tree_leaf0.p;
     A.leaves = d->d_leaves.p;
     if (P->n_tiles) {
-      if (haar && d->spec_fn && !A.trees) {
+      if (d->spec_fn && !A.trees) {
         void* params[] = {&A};
         CC_HIP(hipModuleLaunchKernel(d->spec_fn, (unsigned)P->n_tiles, (unsigned)nf, 1, EVAL_THREADS, 1, 1, (unsigned)d->lds, st, params, nullptr));
       } else if (haar)
@@ -1479,14 +1552,14 @@ static const char kSpecPrelude[] =
     "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
 
 // Compiles `src` for `arch`; identical (source, options) pairs are served from a per-process cache.
-static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, std::vector<char>& code) {
+static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, bool lbp, std::vector<char>& code) {
   static std::mutex mu;
   static std::map<std::string, std::vector<char>> cache;
   const std::string o_arch = "--offload-arch=" + arch, o_k = "-DCC_SPEC_STAGES=" + std::to_string(n_stages);
   const std::string o_ty = "-DCC_TILE_Y=" + std::to_string(TILE_Y), o_th = "-DCC_EVAL_THREADS=" + std::to_string(EVAL_THREADS);
   // same code generation rules as the ahead-of-time build (Makefile): no FMA contraction, no fast-math
-  const char* opts[] = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str()};
-  const int n_opts = (int)(sizeof(opts) / sizeof(opts[0]));
+  const char* opts[] = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str(), "-DCC_SPEC_LBP"};
+  const int n_opts = (int)(sizeof(opts) / sizeof(opts[0])) - (lbp ? 0 : 1);
   std::string key;  // everything the code object depends on: options, then the source
   for (int i = 0; i < n_opts; i++) key += std::string(opts[i]) + " ";
   key += "#" + src;
@@ -1697,8 +1770,7 @@ cc_status cc_detector_specialize(cc_detector* d, int n_stages) {
     d->spec_stages = 0;
     return CC_OK;
   }
-  if (d->m.feature_type != CC_FEATURE_HAAR || d->m.max_nodes_per_tree > 1)
-    return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: Haar stump cascades only");
+  if (d->m.max_nodes_per_tree > 1) return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: stump cascades only");
   // bound the generated code: whole stages while the stump count stays under the budget (instruction cache)
   int k = 0, stumps = 0;
   const int budget = 320;
@@ -1717,12 +1789,12 @@ cc_status cc_detector_specialize(cc_detector* d, int n_stages) {
   std::string arch = prop.gcnArchName;
   arch = arch.substr(0, arch.find(':'));
   std::vector<char> code;
-  st = compile_specialised(src, arch, k, code);
+  st = compile_specialised(src, arch, k, d->m.feature_type == CC_FEATURE_LBP, code);
   if (st != CC_OK) return st;
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   CC_HIP(hipModuleLoadData(&mod, code.data()));
-  if (hipModuleGetFunction(&fn, mod, "k_eval_haar_spec") != hipSuccess) {
+  if (hipModuleGetFunction(&fn, mod, "k_eval_spec") != hipSuccess) {
     (void)hipModuleUnload(mod);
     return set_error(CC_ERR_HIP, "cc_detector_specialize: entry point not found in the compiled module");
   }
@@ -1747,8 +1819,7 @@ int cc_detector_specialized_stages(const cc_detector* d) { return d ? d->spec_st
 
 cc_status cc_cascade_compile_specialized(const cc_cascade* c, int n_stages, const char* arch, size_t* code_bytes) {
   if (!c || !arch || !code_bytes) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_compile_specialized: null argument");
-  if (c->m.feature_type != CC_FEATURE_HAAR || c->m.max_nodes_per_tree > 1)
-    return set_error(CC_ERR_UNSUPPORTED, "cc_cascade_compile_specialized: Haar stump cascades only");
+  if (c->m.max_nodes_per_tree > 1) return set_error(CC_ERR_UNSUPPORTED, "cc_cascade_compile_specialized: stump cascades only");
   const int k = std::max(1, std::min<int>({n_stages, (int)c->m.stage_ntrees.size(), MAX_STAGES}));
   std::string src = kSpecPrelude;
   src += "namespace ccamd {\n";
@@ -1759,7 +1830,7 @@ cc_status cc_cascade_compile_specialized(const cc_cascade* c, int n_stages, cons
   if (pos == std::string::npos) return set_error(CC_ERR_HIP, "cc_cascade_compile_specialized: kernel source has no specialisation marker");
   src.replace(pos, marker.size(), spec_stage_source(c->m, k));
   std::vector<char> code;
-  const cc_status st = compile_specialised(src, arch, k, code);
+  const cc_status st = compile_specialised(src, arch, k, c->m.feature_type == CC_FEATURE_LBP, code);
   if (st != CC_OK) return st;
   *code_bytes = code.size();
   return CC_OK;

@@ -175,7 +175,7 @@ typedef struct cc_scale_info {
 CC_API cc_status cc_scale_plan(int win_w, int win_h, int width, int height, const cc_detect_params* p,
                                cc_scale_info* out, int cap, int* n);
 
-/* Run-time specialisation of the cascade kernel for THIS detector's cascade (Haar stump cascades): the first n_stages
+/* Run-time specialisation of the cascade kernel for THIS detector's cascade (Haar or LBP stump cascades): the first n_stages
  * stages (whole stages, capped by a code-size budget) are compiled with hiprtc into straight-line code whose LDS offsets,
  * weights, thresholds and leaf values are immediates; later stages stay table-driven. Same arithmetic, identical results;
  * the cascade kernel runs about 17 % faster on the bench cascade. Takes a few seconds the first time; code objects are

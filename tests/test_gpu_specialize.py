@@ -56,12 +56,24 @@ def test_specialised_tilted_and_other_windows(tmp_path):
     _same_as_oracle(p, orc.load_cascade_xml(path), frame_natural(333, 127, 6), 1.2)
 
 
-def test_specialise_refuses_what_it_does_not_cover(lbp_xml, tmp_path):
-    with pytest.raises(cc.CascadeError, match="Haar stump cascades only"):
-        cc.CascadeClassifier(lbp_xml).specialize(4)
+def test_specialised_lbp_cascade(lbp_xml):
+    """The stock LBP cascade (20 stages, 139 stumps) compiled whole: bit-exact like the table-driven kernel."""
+    o = orc.load_cascade_xml(lbp_xml)
+    p = cc.CascadeClassifier(lbp_xml)
+    assert p.specialize(20) == 20
+    n = _same_as_oracle(p, o, frame_natural(640, 360, 11), 1.1)
+    n += _same_as_oracle(p, o, frame_uniform(300, 200, 12), 1.25)
+    frames = np.stack([frame_natural(480, 270, 40 + i) for i in range(5)])
+    spec = p.detect_batch(frames, 1.1, 2)
+    p.specialize(0)
+    plain = p.detect_batch(frames, 1.1, 2)
+    assert all(a.shape == b.shape and (a == b).all() for a, b in zip(spec, plain))
+
+
+def test_specialise_refuses_what_it_does_not_cover(tmp_path):
     img = frame_natural(320, 240, 3)
     cal = np.stack([img[y:y + 24, x:x + 24] for y in range(0, 200, 9) for x in range(0, 280, 11)])
     trees = cc.CascadeClassifier()
     assert trees.load_from_string(cf.haar_tree_cascade(cal, with_tilted=False))
-    with pytest.raises(cc.CascadeError, match="Haar stump cascades only"):
+    with pytest.raises(cc.CascadeError, match="stump cascades only"):
         trees.specialize(2)
