@@ -1407,18 +1407,44 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     }
     // candidate list overflow: the ordinary path below grows the lists and redoes the pass
   }
-  int pass_frames = d->max_batch;
-  if (want_results && n_frames >= 2) {  // only the last pass's host work is exposed: use a few passes, not two halves
+  // Pass sizes. With results wanted the batch is cut into a few passes so that the host side of pass i (copy-back +
+  // grouping) overlaps the device side of pass i+1 and the pyramid/integrals of pass i+1 overlap the cascade kernel of
+  // pass i. Nothing overlaps the LAST pass's host work, so it carries about half the frames of the others (32 frames ->
+  // 9, 9, 9, 5; a small first pass, to start the cascade kernel earlier, measured no better).
+  std::vector<int> sizes;
+  if (want_results && n_frames >= 2) {
     int passes = 4;
     if (const char* e = std::getenv("CCAMD_PIPELINE_PASSES")) passes = std::max(1, std::atoi(e));
     passes = std::min(passes, n_frames);
-    pass_frames = std::min(d->max_batch, (n_frames + passes - 1) / passes);
-    // the host work of the LAST pass (copy-back + grouping) is the only part nothing overlaps: give it about half the
-    // frames of the others (32 frames in 4 passes -> 9, 9, 9, 5)
-    if (passes >= 3 && !std::getenv("CCAMD_EVEN_PASSES")) {
-      const int big = std::min(d->max_batch, (2 * n_frames + 2 * passes - 2) / (2 * passes - 1));
-      if (big >= 2 && big * (passes - 1) < n_frames) pass_frames = big;
+    const char* explicit_sizes = std::getenv("CCAMD_PASS_SIZES");  // tuning: comma-separated sizes
+    if (explicit_sizes && *explicit_sizes) {
+      for (const char* q = explicit_sizes; *q;) {
+        const int v = std::atoi(q);
+        if (v > 0) sizes.push_back(v);
+        while (*q && *q != ',') q++;
+        if (*q == ',') q++;
+      }
+    } else {
+      int per = (n_frames + passes - 1) / passes;
+      if (passes >= 3 && !std::getenv("CCAMD_EVEN_PASSES")) {
+        const int big = (2 * n_frames + 2 * passes - 2) / (2 * passes - 1);
+        if (big >= 2 && big * (passes - 1) < n_frames) per = big;
+      }
+      for (int f = 0; f < n_frames; f += per) sizes.push_back(std::min(per, n_frames - f));
     }
+  } else {
+    for (int f = 0; f < n_frames; f += d->max_batch) sizes.push_back(std::min(d->max_batch, n_frames - f));
+  }
+  {  // normalise: sizes within max_batch, summing to n_frames
+    std::vector<int> fixed;
+    int left = n_frames;
+    for (size_t i = 0; left > 0; i++) {
+      int v = i < sizes.size() ? sizes[i] : left;
+      v = std::max(1, std::min({v, d->max_batch, left}));
+      fixed.push_back(v);
+      left -= v;
+    }
+    sizes.swap(fixed);
   }
   struct Pass {
     int f0, nf, slot;
@@ -1456,10 +1482,11 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
   Pass prev{};
   bool have_prev = false;
   int slot = 0;
-  for (int f0 = 0; f0 < n_frames; f0 += pass_frames) {
+  int f0 = 0;
+  for (size_t pi = 0; pi < sizes.size(); f0 += sizes[pi], pi++) {
     Pass ps;
     ps.f0 = f0;
-    ps.nf = std::min(pass_frames, n_frames - f0);
+    ps.nf = sizes[pi];
     ps.slot = slot;
     ps.rs = row_stride;
     ps.fs = frame_stride;
