@@ -24,12 +24,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def make_frames(n, w, h, seed0):
-    from tests.util import frame_natural, upscale
+def make_frames(n, w, h, seed0, content="natural"):
+    from tests.util import frame_natural, frame_uniform, upscale
     tm = np.load(os.path.join(ROOT, "data", "face_template_24x24.npy"))
     frames = np.empty((n, h, w), np.uint8)
     for i in range(n):
-        img = frame_natural(w, h, seed0 + i)
+        img = frame_natural(w, h, seed0 + i) if content == "natural" else frame_uniform(w, h, seed0 + i)
         rng = np.random.default_rng(10_000 + seed0 + i)
         for k in (1.0, 1.6, 2.7, 4.5, 8.0):
             s = int(24 * k)
@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--cascade", default=os.path.join(ROOT, "data", "haarcascade_frontalface_synthetic.xml"))
     ap.add_argument("--scale-factor", type=float, default=1.1)
     ap.add_argument("--min-neighbors", type=int, default=3)
+    ap.add_argument("--content", choices=["natural", "uniform"], default="natural",
+                    help="frame distribution of SURVEY 8d config 2: (ii) natural-like 1/f noise (default, the headline) or (i) "
+                         "i.i.d. uniform noise (almost every window dies in stage 0-1)")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--specialize", type=int, default=7, help="stages compiled into the cascade kernel at load time (hiprtc; 0 = "
                                                               "table-driven kernel only)")
@@ -92,7 +95,7 @@ def main():
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     W, H, B = args.width, args.height, args.frames
-    frames_host = make_frames(B, W, H, seed0=rank * B)
+    frames_host = make_frames(B, W, H, seed0=rank * B, content=args.content)
     frames = torch.from_numpy(frames_host).to(dev)  # resident in HBM before the timed region
     clf = cc.CascadeClassifier(args.cascade, device=dev_index, max_batch=B)
     assert not clf.empty(), getattr(clf, "load_error", "")
@@ -179,7 +182,7 @@ def main():
             "visited_windows_frame0": visited0,
             "kernel_specialized_stages": spec_stages,
             "frames_per_gpu_per_step": B,
-            "frame_content": "1/f noise (sigma 40) + 5 pasted face templates",
+            "frame_content": ("1/f noise (sigma 40)" if args.content == "natural" else "i.i.d. uniform noise") + " + 5 pasted face templates",
             "parallelism": f"frames sharded over {world} GPU(s); RCCL gather of detections only",
             "timed_region": "device pipeline only" if args.device_only else
                             "pyramid+integral+cascade eval+skip filter+candidate copy-back+host grouping" + ("+RCCL gather" if world > 1 else ""),
