@@ -1800,7 +1800,8 @@ cc_status cc_detector_specialize(cc_detector* d, int n_stages) {
   if (d->m.max_nodes_per_tree > 1) return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: stump cascades only");
   // bound the generated code: whole stages while the stump count stays under the budget (instruction cache)
   int k = 0, stumps = 0;
-  const int budget = 320;
+  int budget = 320;
+  if (const char* e = std::getenv("CCAMD_SPEC_BUDGET")) budget = std::max(1, std::atoi(e));  // tuning
   while (k < (int)d->m.stage_ntrees.size() && k < n_stages && k < MAX_STAGES && (k == 0 || stumps + d->m.stage_ntrees[(size_t)k] <= budget))
     stumps += d->m.stage_ntrees[(size_t)k++];
   std::string src = kSpecPrelude;
