@@ -54,9 +54,17 @@ __device__ __forceinline__ int find_segment(const int* __restrict__ first, int n
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: pyramid. One thread = 4 horizontally adjacent output pixels of one scale (one u32 store).
+// K1: pyramid. One thread = 4 horizontally adjacent output pixels x RESIZE_ROWS consecutive output rows of one scale.
 // INTER_LINEAR_EXACT: horizontal 8.8 taps exact in 16 bits, vertical exact in 32 bits, (v + 2^15) >> 16.
+// The column taps are looked up once per thread; walking down the rows, the horizontally interpolated values of a source
+// row are reused when the next output row starts on it (the usual case below scale 2), so an output pixel costs about
+// one new source row (2 byte loads) instead of two rows and two table lookups.
 // ------------------------------------------------------------------------------------------------
+constexpr int RESIZE_ROWS = 8;
+__host__ __device__ inline int resize_blocks(int pitch8, int h) {
+  return ((pitch8 / 4) * ((h + RESIZE_ROWS - 1) / RESIZE_ROWS) + 255) / 256;
+}
+
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ frames, size_t row_stride, size_t frame_stride,
                                                 int src_w, int src_h, uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                 const ScaleDev* __restrict__ sd, int nscales,
@@ -66,32 +74,55 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ fram
   const int s = find_segment(blk_first, nscales, blockIdx.x);
   const ScaleDev S = sd[s];
   const int wpr = S.pitch8 >> 2;
-  const int word = (blockIdx.x - blk_first[s]) * 256 + threadIdx.x;
-  const int y = word / wpr, xw = word - y * wpr;
-  if (y >= S.h) return;
+  const int item = (blockIdx.x - blk_first[s]) * 256 + threadIdx.x;
+  const int band = item / wpr, xw = item - band * wpr;
+  const int ya = band * RESIZE_ROWS;
+  if (ya >= S.h) return;
   const uint8_t* src = frames + (size_t)blockIdx.y * frame_stride;
-  const int y0 = yofs[S.ytab_ofs + y];
-  const unsigned wy1 = yw1[S.ytab_ofs + y], wy0 = 256u - wy1;
-  const int y1 = min(y0 + 1, src_h - 1);
-  const uint8_t* r0 = src + (size_t)y0 * row_stride;
-  const uint8_t* r1 = src + (size_t)y1 * row_stride;
-  unsigned packed = 0;
+  int x0[4], x1[4];
+  unsigned wx0[4], wx1[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int x = xw * 4 + k;
-    unsigned v = 0;
-    if (x < S.w) {
-      const int x0 = xofs[S.xtab_ofs + x];
-      const unsigned wx1 = xw1[S.xtab_ofs + x], wx0 = 256u - wx1;
-      const int x1 = min(x0 + 1, src_w - 1);
-      const unsigned h0 = wx0 * r0[x0] + wx1 * r0[x1];
-      const unsigned h1 = wx0 * r1[x0] + wx1 * r1[x1];
-      v = (h0 * wy0 + h1 * wy1 + (1u << 15)) >> 16;
-    }
-    packed |= v << (8 * k);
+    const int x = min(xw * 4 + k, S.w - 1);  // columns past the image (row padding) are masked out below
+    x0[k] = xofs[S.xtab_ofs + x];
+    wx1[k] = xw1[S.xtab_ofs + x];
+    wx0[k] = 256u - wx1[k];
+    x1[k] = min(x0[k] + 1, src_w - 1);
   }
-  uint8_t* dst = pyr + (size_t)blockIdx.y * pyr_frame_bytes + S.img_ofs + (size_t)y * S.pitch8;
-  reinterpret_cast<unsigned*>(dst)[xw] = packed;
+  auto hrow = [&](int yy, unsigned* h) {  // horizontal interpolation of source row yy at the 4 columns
+    const uint8_t* r = src + (size_t)yy * row_stride;
+#pragma unroll
+    for (int k = 0; k < 4; k++) h[k] = wx0[k] * r[x0[k]] + wx1[k] * r[x1[k]];
+  };
+  unsigned hc[4] = {0, 0, 0, 0};
+  int cached = -1;  // source row whose interpolation hc holds
+  uint8_t* dst = pyr + (size_t)blockIdx.y * pyr_frame_bytes + S.img_ofs;
+  const int yb = min(ya + RESIZE_ROWS, S.h);
+  for (int y = ya; y < yb; y++) {
+    const int y0 = yofs[S.ytab_ofs + y];
+    const unsigned wy1 = yw1[S.ytab_ofs + y], wy0 = 256u - wy1;
+    const int y1 = min(y0 + 1, src_h - 1);
+    unsigned h0[4], h1[4];
+    if (y0 == cached) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) h0[k] = hc[k];
+    } else
+      hrow(y0, h0);
+    if (y1 == y0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) h1[k] = h0[k];
+    } else
+      hrow(y1, h1);
+    unsigned packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned v = (h0[k] * wy0 + h1[k] * wy1 + (1u << 15)) >> 16;
+      if (xw * 4 + k < S.w) packed |= v << (8 * k);
+      hc[k] = h1[k];
+    }
+    cached = y1;
+    reinterpret_cast<unsigned*>(dst + (size_t)y * S.pitch8)[xw] = packed;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1070,7 +1101,7 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
     mask_ofs += (long long)S.nxw * g.ny;
     win_ofs += (long long)g.nx * g.ny;
     P->integral_elems += (long long)(g.w + 1) * (g.h + 1);
-    resize_first[i + 1] = resize_first[i] + ((S.pitch8 / 4) * g.h + 255) / 256;
+    resize_first[i + 1] = resize_first[i] + resize_blocks(S.pitch8, g.h);
     S.nbands = (g.h + INT_BAND - 1) / INT_BAND;
     S.h_ofs = h_ofs;
     h_ofs += (long long)S.nbands * S.pitchI;
@@ -2010,7 +2041,7 @@ cc_status cc_resize_linear_exact_u8(int device, const uint8_t* src, int sw, int 
   linear_exact_taps(sw, dw, tx);
   linear_exact_taps(sh, dh, ty);
   std::vector<ScaleDev> sd{S};
-  const int nblk = ((S.pitch8 / 4) * dh + 255) / 256;
+  const int nblk = resize_blocks(S.pitch8, dh);
   std::vector<int> first{0, nblk};
   DevBuf<ScaleDev> d_sd;
   DevBuf<int> d_first, d_xofs, d_yofs;
@@ -2283,7 +2314,7 @@ cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int he
     img_ofs += (long long)align_up(S.pitch8 * S.h, 16);
     int_ofs += (long long)S.pitchI * (S.h + 1);
     h_ofs += (long long)S.nbands * S.pitchI;
-    resize_first[i + 1] = resize_first[i] + ((S.pitch8 / 4) * S.h + 255) / 256;
+    resize_first[i + 1] = resize_first[i] + resize_blocks(S.pitch8, S.h);
     band_first[i + 1] = band_first[i] + S.nbands;
     col_first[i + 1] = col_first[i] + (S.pitchI / 4 + 63) / 64;
     diag_first[i + 1] = diag_first[i] + (S.w + S.h - 1 + 63) / 64;
