@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_integral_band(const uint8_t* __restrict
                                                        int32_t* __restrict__ integ, size_t int_frame_elems, int nchan,
                                                        int32_t* __restrict__ hbuf, size_t h_frame_elems,
                                                        const ScaleDev* __restrict__ sd, int nscales,
-                                                       const int* __restrict__ band_first, int total_bands) {
+                                                       const int* __restrict__ band_first, int total_bands, int sq_odd_rows_only) {
   const int lane = threadIdx.x & 63;
   const int gb = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gb >= total_bands) return;
@@ -232,7 +232,12 @@ __global__ __launch_bounds__(256) void k_integral_band(const uint8_t* __restrict
       }
       if (FINAL && col_ok && r < nrows) {
         *reinterpret_cast<int4*>(osum + (size_t)r * S.pitchI + px) = make_int4((int)vs.x, (int)vs.y, (int)vs.z, (int)vs.w);
-        if (SQ) *reinterpret_cast<int4*>(osq + (size_t)r * S.pitchI + px) = make_int4((int)vq.x, (int)vq.y, (int)vq.z, (int)vq.w);
+        // The detector reads the squared sums only at the 4 corners of each window's variance rectangle: with a scan
+        // step of 2 and an even window height those are odd integral rows; the even rows are never read, so they are
+        // not written (a quarter of the integral bytes of such a scale).
+        const bool sq_row_needed = !(sq_odd_rows_only && S.ystep == 2) || ((r0 + 1 + r) & 1);
+        if (SQ && sq_row_needed)
+          *reinterpret_cast<int4*>(osq + (size_t)r * S.pitchI + px) = make_int4((int)vq.x, (int)vq.y, (int)vq.z, (int)vq.w);
       }
     }
     if (!FINAL && col_ok) {
@@ -1202,21 +1207,21 @@ static void collect_events(cc_detector* d) {
 // Integral images of every scale of nf frames: band totals, carry down the bands, finished integral.
 static void launch_integral(hipStream_t st, bool sq, const uint8_t* pyr, size_t pyr_frame_bytes, int32_t* integ,
                             size_t int_frame_elems, int nchan /* channel stride of integ / hbuf */, int32_t* hbuf, size_t h_frame_elems, const ScaleDev* sd, int ns,
-                            const int* band_first, int n_bands, const int* col_first, int n_col_blocks, int nf) {
+                            const int* band_first, int n_bands, const int* col_first, int n_col_blocks, int nf, int sq_odd_rows_only = 0) {
   const dim3 grid((n_bands + 3) / 4, nf);
   if (sq)
     hipLaunchKernelGGL((k_integral_band<true, false>), grid, dim3(256), 0, st, pyr, pyr_frame_bytes, integ, int_frame_elems, nchan,
-                       hbuf, h_frame_elems, sd, ns, band_first, n_bands);
+                       hbuf, h_frame_elems, sd, ns, band_first, n_bands, 0);
   else
     hipLaunchKernelGGL((k_integral_band<false, false>), grid, dim3(256), 0, st, pyr, pyr_frame_bytes, integ, int_frame_elems, nchan,
-                       hbuf, h_frame_elems, sd, ns, band_first, n_bands);
+                       hbuf, h_frame_elems, sd, ns, band_first, n_bands, 0);
   hipLaunchKernelGGL(k_integral_carry, dim3(n_col_blocks, nf, sq ? 2 : 1), dim3(64), 0, st, hbuf, h_frame_elems, nchan, sd, ns, col_first);
   if (sq)
     hipLaunchKernelGGL((k_integral_band<true, true>), grid, dim3(256), 0, st, pyr, pyr_frame_bytes, integ, int_frame_elems, nchan,
-                       hbuf, h_frame_elems, sd, ns, band_first, n_bands);
+                       hbuf, h_frame_elems, sd, ns, band_first, n_bands, sq_odd_rows_only);
   else
     hipLaunchKernelGGL((k_integral_band<false, true>), grid, dim3(256), 0, st, pyr, pyr_frame_bytes, integ, int_frame_elems, nchan,
-                       hbuf, h_frame_elems, sd, ns, band_first, n_bands);
+                       hbuf, h_frame_elems, sd, ns, band_first, n_bands, sq_odd_rows_only);
 }
 
 // Device pipeline for up to max_batch frames already resident on the device. Leaves the filtered candidate list
@@ -1256,7 +1261,8 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   {
     EvScope ev(d, EV_INTEGRAL, fs);
     launch_integral(fs, haar, d->d_pyr.p, P->pyr_frame_bytes, d->d_integ[slot].p, P->int_frame_elems, nchan, d->d_hbuf.p,
-                    P->h_frame_elems, P->d_sd.p, ns, P->d_band_first.p, P->n_bands, P->d_col_first.p, P->n_col_blocks, nf);
+                    P->h_frame_elems, P->d_sd.p, ns, P->d_band_first.p, P->n_bands, P->d_col_first.p, P->n_col_blocks, nf,
+                    /*sq_odd_rows_only=*/(d->m.win_h % 2 == 0 && !std::getenv("CCAMD_FULL_SQSUM")) ? 1 : 0);
     if (tilt) {
       hipLaunchKernelGGL(k_diag_sums, dim3(P->n_diag_blocks, nf, 2), dim3(64), 0, fs, d->d_pyr.p, P->pyr_frame_bytes, d->d_diag.p,
                          P->int_frame_elems, P->d_sd.p, ns, P->d_diag_first.p);
