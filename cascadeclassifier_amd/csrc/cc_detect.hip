@@ -234,10 +234,14 @@ __global__ __launch_bounds__(256) void k_integral_band(const uint8_t* __restrict
         *reinterpret_cast<int4*>(osum + (size_t)r * S.pitchI + px) = make_int4((int)vs.x, (int)vs.y, (int)vs.z, (int)vs.w);
         // The detector reads the squared sums only at the 4 corners of each window's variance rectangle: with a scan
         // step of 2 and an even window height those are odd integral rows; the even rows are never read, so they are
-        // not written (a quarter of the integral bytes of such a scale).
-        const bool sq_row_needed = !(sq_odd_rows_only && S.ystep == 2) || ((r0 + 1 + r) & 1);
-        if (SQ && sq_row_needed)
-          *reinterpret_cast<int4*>(osq + (size_t)r * S.pitchI + px) = make_int4((int)vq.x, (int)vq.y, (int)vq.z, (int)vq.w);
+        // not written
+        if (SQ) {
+          if (sq_odd_rows_only && S.ystep == 2) {
+            // ... and of those rows only the odd columns, which are packed (column 2c+1 at c): 8 bytes per lane
+            if ((r0 + 1 + r) & 1) *reinterpret_cast<int2*>(osq + (size_t)r * S.pitchI + (px >> 1)) = make_int2((int)vq.y, (int)vq.w);
+          } else
+            *reinterpret_cast<int4*>(osq + (size_t)r * S.pitchI + px) = make_int4((int)vq.x, (int)vq.y, (int)vq.z, (int)vq.w);
+        }
       }
     }
     if (!FINAL && col_ok) {
@@ -1237,6 +1241,8 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   CC_HIP(d->d_counts[slot].ensure(2));
   CC_HIP(hipMemsetAsync(d->d_counts[slot].p, 0, 2 * sizeof(int), st));
   if (ns == 0 || nf == 0) return CC_OK;
+  // even window sizes: the variance rectangle's corners of step-2 scales sit on odd rows and odd columns only
+  const int sq_compact = (haar && d->m.win_w % 2 == 0 && d->m.win_h % 2 == 0 && !std::getenv("CCAMD_FULL_SQSUM")) ? 1 : 0;
   CC_HIP(d->d_pyr.ensure(P->pyr_frame_bytes * (size_t)d->max_batch));
   CC_HIP(d->d_integ[slot].ensure(P->int_frame_elems * (size_t)nchan * (size_t)d->max_batch));
   CC_HIP(d->d_hbuf.ensure(std::max<size_t>(P->h_frame_elems * (size_t)nchan * (size_t)d->max_batch, 4)));
@@ -1262,7 +1268,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     EvScope ev(d, EV_INTEGRAL, fs);
     launch_integral(fs, haar, d->d_pyr.p, P->pyr_frame_bytes, d->d_integ[slot].p, P->int_frame_elems, nchan, d->d_hbuf.p,
                     P->h_frame_elems, P->d_sd.p, ns, P->d_band_first.p, P->n_bands, P->d_col_first.p, P->n_col_blocks, nf,
-                    /*sq_odd_rows_only=*/(d->m.win_h % 2 == 0 && !std::getenv("CCAMD_FULL_SQSUM")) ? 1 : 0);
+                    /*sq_odd_rows_only=*/sq_compact);
     if (tilt) {
       hipLaunchKernelGGL(k_diag_sums, dim3(P->n_diag_blocks, nf, 2), dim3(64), 0, fs, d->d_pyr.p, P->pyr_frame_bytes, d->d_diag.p,
                          P->int_frame_elems, P->d_sd.p, ns, P->d_diag_first.p);
@@ -1291,6 +1297,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.stop_after = d->stop_after;
     A.split_stumps = d->split_stumps;
     A.early_skip = std::getenv("CCAMD_NO_EARLY_SKIP") ? 0 : 1;
+    A.sq_compact = sq_compact;
     A.stage_thr = d->d_stage_thr.p;
     A.masks = d->d_masks.p;
     A.mask_frame_words = P->mask_frame_words;
