@@ -1,0 +1,50 @@
+"""Randomised differential test of the detector against the CPU oracle: image sizes (incl. ones barely larger than the
+window and ragged widths), scale factors, min/max object sizes and minNeighbors drawn from fixed seeds; Haar (table-driven
+and specialised kernel) and LBP. Everything compared exactly: ungrouped candidates and grouped rectangles."""
+import numpy as np
+import pytest
+
+import cascadeclassifier_amd as cc
+from oracle import oracle as orc
+from tests.util import frame_natural, frame_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(seed, n):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        w = int(rng.choice([24, 25, 31, 64, 65, 97, 128, 191, 257, 320, 403]))
+        h = int(rng.choice([24, 26, 33, 48, 77, 100, 129, 200, 301]))
+        sf = float(rng.choice([1.05, 1.1, 1.2, 1.5, 2.0, 3.0, 4.0]))
+        mn = int(rng.choice([0, 1, 2, 3, 5]))
+        mins = None if rng.random() < 0.6 else (int(rng.integers(24, 60)),) * 2
+        maxs = None if rng.random() < 0.6 else (int(rng.integers(40, 200)),) * 2
+        content = frame_natural if rng.random() < 0.7 else frame_uniform
+        yield w, h, sf, mn, mins, maxs, content(w, h, 1000 * seed + i)
+
+
+@pytest.mark.parametrize("which", ["haar", "haar_specialised", "lbp"])
+def test_random_configurations(which, haar_xml, lbp_xml):
+    xml = lbp_xml if which == "lbp" else haar_xml
+    o = orc.load_cascade_xml(xml)
+    p = cc.CascadeClassifier(xml)
+    if which == "haar_specialised":
+        assert p.specialize(3) == 3
+    total = 0
+    for w, h, sf, mn, mins, maxs, img in _cases({"haar": 1, "haar_specialised": 2, "lbp": 3}[which], 40):
+        kw, okw = {}, {}
+        if mins:
+            kw["minSize"] = mins
+            okw["min_size"] = mins
+        if maxs:
+            kw["maxSize"] = maxs
+            okw["max_size"] = maxs
+        ref = orc.detect_raw(o, img, sf, nthreads=4, **okw)
+        raw = p.detect_raw(img, sf, **kw)
+        assert raw.shape == ref.candidates.shape and (raw == ref.candidates).all(), (w, h, sf, mins, maxs)
+        a = p.detectMultiScale(img, sf, mn, **kw)
+        b = orc.detect_multiscale(o, img, sf, mn, nthreads=4, **okw)
+        assert a.shape == b.shape and (a == b).all(), (w, h, sf, mn, mins, maxs)
+        total += len(raw)
+    assert total > 0
