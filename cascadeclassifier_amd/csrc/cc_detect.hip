@@ -6,7 +6,9 @@
 // Data layout in HBM (per frame slot f of a batch; all slabs are sized for max_batch frames):
 //   pyramid  u8   : scale s at pyr + f*pyr_frame_bytes + img_ofs[s], row pitch pitch8[s] (multiple of 4)
 //   integral i32  : sum   at integ + (f*nchan + 0)*int_frame_elems + int_ofs[s], (h+1) rows x pitchI[s] (multiple of 4)
-//                   sqsum at integ + (f*nchan + 1)*int_frame_elems + int_ofs[s]   (Haar only; u32 wrap-around)
+//                   sqsum at integ + (f*nchan + 1)*int_frame_elems + int_ofs[s]   (Haar only; u32 wrap-around). With an even
+//                   window size, scales scanned with step 2 keep only what the variance test reads: odd rows, and
+//                   of those the odd columns packed (column 2c+1 at c)
 //   rej0 mask u64 : bit gx&63 of word mask_ofs[s] + gy*nxw[s] + (gx>>6) = window (gx,gy) was rejected AT STAGE 0
 //   candidates    : one global list {frame, scale, gx, gy} + counter; the filtered list adds the output rectangle.
 //
