@@ -162,6 +162,13 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "r01_traffic_k_eval_haar.json")
     if inf["feature_type"] == 0 and os.path.exists(tfile) and (W, H) == (1920, 1080) and abs(args.scale_factor - 1.1) < 1e-12:
         traffic = round(json.load(open(tfile))["hbm_bytes_per_frame"] * frames_per_launch)
+    # secondary limiter: LDS bandwidth of the corner gathers, from the committed PMC pass of the same kernel
+    secondary = None
+    pfile = os.path.join(ROOT, "profiles", "r01_pmc_eval.json")
+    if inf["feature_type"] == 0 and spec_stages and os.path.exists(pfile) and (W, H) == (1920, 1080):
+        pj = json.load(open(pfile))
+        secondary = {"limiter": "LDS", "lds_pipeline_busy": pj["lds_pipeline_busy"], "lds_bank_conflict_share": pj["lds_bank_conflict_share"],
+                     "valu_busy": pj["valu_busy"], "source": "profiles/r01_pmc_eval.json (tools/pmc_eval.sh)"}
     out = {
         "metric": "detection Mwindows/sec (1080p, haarcascade_frontalface) + achieved HBM GB/s",
         "value": round(value, 3),
@@ -202,6 +209,7 @@ def main():
             "algorithmic_bytes_per_launch": round(eval_bytes_per_frame * frames_per_launch),
             "frames_per_launch": frames_per_launch,
             "avg_launch_ms": round(eval_ms, 4),
+            "secondary": secondary,
         },
     }
     if rank == 0 and world == 1 and args.cpu_frames > 0:

@@ -18,6 +18,16 @@ for k,v in agg.items():
         print(k, {c:round(x) for c,x in m.items()})
         if m.get("SQ_LDS_IDX_ACTIVE"):
             print("  LDS conflict share of LDS-active cycles:", round(m["SQ_LDS_BANK_CONFLICT"]/m["SQ_LDS_IDX_ACTIVE"],3))
+        import json
+        cus, simds = 256, 1024
+        cyc = m["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+        out = {"kernel": k, "counters_per_launch": {c: round(x) for c, x in m.items()},
+               "kernel_cycles": round(cyc), "lds_pipeline_busy": round(m["SQ_LDS_IDX_ACTIVE"] / cus / cyc, 3),
+               "lds_bank_conflict_share": round(m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"], 3),
+               "valu_busy": round(m["SQ_INSTS_VALU"] * 4 / simds / cyc, 3),
+               "how": "rocprofv3 --kernel-trace --pmc (one pass, no stream overlap), bench.py --cpu-frames 0 --steps 2 --warmup 1; LDS busy = SQ_LDS_IDX_ACTIVE / 256 CUs / kernel cycles (GRBM_GUI_ACTIVE / 8 XCDs); VALU busy = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / kernel cycles"}
+        json.dump(out, open("$out/summary.json", "w"), indent=1)
+        print("  LDS pipeline busy:", out["lds_pipeline_busy"], " VALU busy:", out["valu_busy"])
         if m.get("SQ_BUSY_CYCLES"):
             print("  LDS active / SQ busy:", round(m["SQ_LDS_IDX_ACTIVE"]/m["SQ_BUSY_CYCLES"],3), " VALU active / SQ busy:", round(m["SQ_ACTIVE_INST_VALU"]/m["SQ_BUSY_CYCLES"],3))
 PY
