@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (64 = BASELINE configs[3]: 512 frames over 8 GPUs)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cascade", default=os.path.join(ROOT, "data", "haarcascade_frontalface_synthetic.xml"))
