@@ -634,6 +634,7 @@ struct cc_detector {
   uint8_t* h_frame = nullptr;  // pinned staging copy of a single host image (graph path)
   size_t h_frame_bytes = 0;
   int use_graph = 1;
+  int early_skip = 1, full_sqsum = 0, pipeline_passes = 4, even_passes = 0;  // tuning knobs, read once at creation
   hipStream_t copy_stream = nullptr;
   hipEvent_t pass_done[2] = {nullptr, nullptr};
   int cand_cap = 0;
@@ -1244,7 +1245,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   CC_HIP(hipMemsetAsync(d->d_counts[slot].p, 0, 2 * sizeof(int), st));
   if (ns == 0 || nf == 0) return CC_OK;
   // even window sizes: the variance rectangle's corners of step-2 scales sit on odd rows and odd columns only
-  const int sq_compact = (haar && d->m.win_w % 2 == 0 && d->m.win_h % 2 == 0 && !std::getenv("CCAMD_FULL_SQSUM")) ? 1 : 0;
+  const int sq_compact = (haar && d->m.win_w % 2 == 0 && d->m.win_h % 2 == 0 && !d->full_sqsum) ? 1 : 0;
   CC_HIP(d->d_pyr.ensure(P->pyr_frame_bytes * (size_t)d->max_batch));
   CC_HIP(d->d_integ[slot].ensure(P->int_frame_elems * (size_t)nchan * (size_t)d->max_batch));
   CC_HIP(d->d_hbuf.ensure(std::max<size_t>(P->h_frame_elems * (size_t)nchan * (size_t)d->max_batch, 4)));
@@ -1298,7 +1299,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.wave_below = d->wave_below;
     A.stop_after = d->stop_after;
     A.split_stumps = d->split_stumps;
-    A.early_skip = std::getenv("CCAMD_NO_EARLY_SKIP") ? 0 : 1;
+    A.early_skip = d->early_skip;
     A.sq_compact = sq_compact;
     A.stage_thr = d->d_stage_thr.p;
     A.masks = d->d_masks.p;
@@ -1459,9 +1460,7 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
   // 9, 9, 9, 5; a small first pass, to start the cascade kernel earlier, measured no better).
   std::vector<int> sizes;
   if (want_results && n_frames >= 2) {
-    int passes = 4;
-    if (const char* e = std::getenv("CCAMD_PIPELINE_PASSES")) passes = std::max(1, std::atoi(e));
-    passes = std::min(passes, n_frames);
+    const int passes = std::min(d->pipeline_passes, n_frames);
     const char* explicit_sizes = std::getenv("CCAMD_PASS_SIZES");  // tuning: comma-separated sizes
     if (explicit_sizes && *explicit_sizes) {
       for (const char* q = explicit_sizes; *q;) {
@@ -1472,7 +1471,7 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       }
     } else {
       int per = (n_frames + passes - 1) / passes;
-      if (passes >= 3 && !std::getenv("CCAMD_EVEN_PASSES")) {
+      if (passes >= 3 && !d->even_passes) {
         const int big = (2 * n_frames + 2 * passes - 2) / (2 * passes - 1);
         if (big >= 2 && big * (passes - 1) < n_frames) per = big;
       }
@@ -1766,6 +1765,10 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   d->split_stumps = exact ? 1 : 0;
   if (const char* e = std::getenv("CCAMD_SPLIT_STUMPS")) d->split_stumps = d->split_stumps && std::atoi(e) != 0;
   if (const char* e = std::getenv("CCAMD_DEBUG_STOP_AFTER_STAGE")) d->stop_after = std::atoi(e);  // timing experiments
+  d->early_skip = std::getenv("CCAMD_NO_EARLY_SKIP") ? 0 : 1;
+  d->full_sqsum = std::getenv("CCAMD_FULL_SQSUM") ? 1 : 0;
+  if (const char* e = std::getenv("CCAMD_PIPELINE_PASSES")) d->pipeline_passes = std::max(1, std::atoi(e));
+  d->even_passes = std::getenv("CCAMD_EVEN_PASSES") ? 1 : 0;
   if (const char* e = std::getenv("CCAMD_DEBUG_EXTRA_LDS")) {  // occupancy experiments: pad the per-block LDS request
     d->lds += (size_t)std::max(0, std::atoi(e));
     if (d->lds > 64 * 1024)
