@@ -100,6 +100,9 @@ struct SplitOrdArgs {
 // 2 = LDS, 8-B entries (regression with responses +-1: entry = response * w, w = |entry|; classification: entry = w with
 // the class in the sign bit; NaN = not in the node). A wavefront's 64 lanes gather 64 unrelated entries per rank, which
 // costs ~64 L2 requests from global memory but a few LDS cycles from a block-resident copy.
+#ifndef CC_SPLIT_UNROLL
+#define CC_SPLIT_UNROLL 16  // ranks whose loads are in flight per thread before the sequential part consumes them
+#endif
 template <int MODE, class TI, int TAB>
 __global__ __launch_bounds__(1024) void k_split_ord(SplitOrdArgs A) {
   extern __shared__ double l_tab[];
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(1024) void k_split_ord(SplitOrdArgs A) {
   double best_val = -1.0;
   int best_i = -1, count = 0;
   float prev = 0.f, vl = 0.f, vr = 0.f;
-  constexpr int U = 8;
+  constexpr int U = CC_SPLIT_UNROLL;
   for (int r0 = 0; r0 < A.n_pre; r0 += U) {
     float v[U];
     SplitEntry e[U];
