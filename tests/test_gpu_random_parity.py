@@ -48,3 +48,19 @@ def test_random_configurations(which, haar_xml, lbp_xml):
         assert a.shape == b.shape and (a == b).all(), (w, h, sf, mn, mins, maxs)
         total += len(raw)
     assert total > 0
+
+
+def test_large_frames_4k_and_extreme_aspect(haar_xml):
+    """Index arithmetic at sizes well beyond Full HD: one 3840x2160 frame and a 8000x40 strip, candidates and grouped
+    rectangles identical to the oracle (table-driven and specialised kernel)."""
+    o = orc.load_cascade_xml(haar_xml)
+    p = cc.CascadeClassifier(haar_xml)
+    for img, sf in ((frame_natural(3840, 2160, 77), 1.25), (frame_natural(8000, 40, 78), 1.1)):
+        ref = orc.detect_raw(o, img, sf, nthreads=8)
+        want = orc.detect_multiscale(o, img, sf, 3, nthreads=8)
+        for k in (0, 4):
+            p.specialize(k)
+            raw = p.detect_raw(img, sf)
+            assert raw.shape == ref.candidates.shape and (raw == ref.candidates).all()
+            got = p.detectMultiScale(img, sf, 3)
+            assert got.shape == want.shape and (got == want).all()
