@@ -64,3 +64,41 @@ def test_large_frames_4k_and_extreme_aspect(haar_xml):
             assert raw.shape == ref.candidates.shape and (raw == ref.candidates).all()
             got = p.detectMultiScale(img, sf, 3)
             assert got.shape == want.shape and (got == want).all()
+
+
+def test_independent_detectors_on_concurrent_host_threads(haar_xml, lbp_xml):
+    """Serving shape: several host threads, each with its own detector (own streams, buffers, specialised module), on one
+    GPU at the same time. ctypes drops the GIL inside the library, so the calls really overlap."""
+    import threading
+    frames = np.stack([frame_natural(480, 270, 300 + i) for i in range(6)])
+    cfg = [(haar_xml, 0), (haar_xml, 3), (lbp_xml, 0), (haar_xml, 3)]
+    serial = []
+    for xml, k in cfg:
+        p = cc.CascadeClassifier(xml)
+        serial.append([r.copy() for r in p.detect_batch(frames, 1.1, 2)])
+    results = [None] * len(cfg)
+    errors = []
+
+    def work(i):
+        try:
+            xml, k = cfg[i]
+            p = cc.CascadeClassifier(xml)
+            if k:
+                p.specialize(k)
+            out = None
+            for _ in range(5):
+                out = p.detect_batch(frames, 1.1, 2)
+                one = p.detectMultiScale(frames[2], 1.1, 2)
+                assert one.shape == out[2].shape and (one == out[2]).all()
+            results[i] = out
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(cfg))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for got, want in zip(results, serial):
+        assert all(a.shape == b.shape and (a == b).all() for a, b in zip(got, want))
