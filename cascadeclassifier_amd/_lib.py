@@ -98,6 +98,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_int64)]),
     "cc_scale_plan": (_i, [_i, _i, _i, _i, C.POINTER(DetectParams), _vp, _i, C.POINTER(_i)]),
     "cc_detector_specialize": (_i, [_vp, _i]),
+    "cc_detector_specialize_async": (_i, [_vp, _i]),
     "cc_detector_specialized_stages": (_i, [_vp]),
     "cc_cascade_compile_specialized": (_i, [_vp, _i, C.c_char_p, C.POINTER(C.c_size_t)]),
     "cc_detector_set_profiling": (_i, [_vp, _i]),

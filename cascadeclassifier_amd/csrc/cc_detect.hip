@@ -28,6 +28,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 
@@ -625,6 +626,13 @@ struct cc_detector {
   hipModule_t spec_mod = nullptr;
   hipFunction_t spec_fn = nullptr;
   int spec_stages = 0;
+  // background build of the specialised module (cc_detector_specialize_async / CCAMD_AUTO_SPECIALIZE): a host thread
+  // generates and compiles; the next detection call on the owning thread loads the module and switches over
+  std::thread spec_thread;
+  std::atomic<int> spec_bg_state{0};  // 0 idle, 1 building, 2 ready to install, 3 failed
+  std::vector<char> spec_bg_code;
+  int spec_bg_stages = 0;
+  std::string spec_bg_error;
   DevBuf<unsigned long long> d_masks;
   DevBuf<CandRaw> d_cands;
   // Results of a pass are double-buffered so that the host can fetch and group pass i while the device runs pass i+1.
@@ -654,6 +662,7 @@ struct cc_detector {
     if (own_stream) (void)hipStreamDestroy(own_stream);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (front_stream) (void)hipStreamDestroy(front_stream);
+    if (spec_thread.joinable()) spec_thread.join();
     if (spec_mod) (void)hipModuleUnload(spec_mod);
     for (hipEvent_t e : {pass_done[0], pass_done[1], front_done[0], front_done[1], eval_done[0], eval_done[1], batch_begin})
       if (e) (void)hipEventDestroy(e);
@@ -1359,6 +1368,8 @@ static cc_status check_frame_args(const cc_detector* d, const uint8_t* frames, i
   return CC_OK;
 }
 
+static void spec_poll(cc_detector* d);  // installs a finished background specialisation
+
 // Runs the batch in passes. `consume` (optional) receives the filtered candidates of each pass (frame indices made
 // global) on the calling thread. With two or more frames the batch is cut into at least two passes and the host side
 // of pass i (copy-back + consume) overlaps the device side of pass i+1.
@@ -1368,6 +1379,7 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
                            Consume consume) {
   cc_status stt = ensure_device(d->device);
   if (stt != CC_OK) return stt;
+  spec_poll(d);
   Plan* P = nullptr;
   stt = build_plan(d, width, height, *p, &P);
   if (stt != CC_OK) return stt;
@@ -1714,6 +1726,97 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
   return CC_OK;
 }
 
+
+// Host half of the specialisation: source for the first stages (whole stages within the code-size budget) compiled for
+// `arch`. No device calls: safe on a background thread.
+static cc_status spec_build(const Cascade& m, int n_stages, const std::string& arch, std::vector<char>& code, int& k_out) {
+  if (m.max_nodes_per_tree > 1) return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: stump cascades only");
+  int k = 0, stumps = 0;
+  int budget = 320;  // instruction cache: more stages measured no faster, 12 stages slower
+  if (const char* e = std::getenv("CCAMD_SPEC_BUDGET")) budget = std::max(1, std::atoi(e));  // tuning
+  while (k < (int)m.stage_ntrees.size() && k < n_stages && k < MAX_STAGES && (k == 0 || stumps + m.stage_ntrees[(size_t)k] <= budget))
+    stumps += m.stage_ntrees[(size_t)k++];
+  std::string src = kSpecPrelude;
+  src += "namespace ccamd {\n";
+  src += kEvalKernelSrc;
+  src += "\n}  // namespace ccamd\n";
+  const std::string marker = "//@@CC_SPEC_FUNCTIONS@@";
+  const size_t pos = src.find(marker);
+  if (pos == std::string::npos) return set_error(CC_ERR_HIP, "cc_detector_specialize: kernel source has no specialisation marker");
+  src.replace(pos, marker.size(), spec_stage_source(m, k));
+  k_out = k;
+  return compile_specialised(src, arch, k, m.feature_type == CC_FEATURE_LBP, code);
+}
+
+// Device half: load the code object and make it the detector's cascade kernel. Owning thread only.
+static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int k) {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  CC_HIP(hipModuleLoadData(&mod, code.data()));
+  if (hipModuleGetFunction(&fn, mod, "k_eval_spec") != hipSuccess) {
+    (void)hipModuleUnload(mod);
+    return set_error(CC_ERR_HIP, "cc_detector_specialize: entry point not found in the compiled module");
+  }
+  if (d->lds > 64 * 1024) {  // same opt-in as the ahead-of-time kernels (cc_detector_create)
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipModuleUnload(mod);
+      return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: %zu bytes of LDS per tile cannot be requested for a run-time module (%s)",
+                       d->lds, hipGetErrorString(e));
+    }
+  }
+  CC_HIP(hipStreamSynchronize(d->stream));
+  if (d->spec_mod) (void)hipModuleUnload(d->spec_mod);
+  d->spec_mod = mod;
+  d->spec_fn = fn;
+  d->spec_stages = k;
+  return CC_OK;
+}
+
+static cc_status device_arch(int device, std::string& arch) {
+  hipDeviceProp_t prop;
+  CC_HIP(hipGetDeviceProperties(&prop, device));
+  arch = prop.gcnArchName;
+  arch = arch.substr(0, arch.find(':'));
+  return CC_OK;
+}
+
+// Picks up a finished background build (called at the start of every detection call).
+static void spec_poll(cc_detector* d) {
+  const int st = d->spec_bg_state.load(std::memory_order_acquire);
+  if (st != 2 && st != 3) return;
+  if (d->spec_thread.joinable()) d->spec_thread.join();
+  if (st == 2 && spec_install(d, d->spec_bg_code, d->spec_bg_stages) != CC_OK) d->spec_bg_error = cc_last_error();
+  d->spec_bg_code.clear();
+  d->spec_bg_state.store(0, std::memory_order_release);
+}
+
+static cc_status spec_start_background(cc_detector* d, int n_stages) {
+  if (d->m.max_nodes_per_tree > 1) return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: stump cascades only");
+  if (d->spec_bg_state.load(std::memory_order_acquire) == 1) return CC_OK;  // a build is already running
+  spec_poll(d);
+  std::string arch;
+  cc_status st = device_arch(d->device, arch);
+  if (st != CC_OK) return st;
+  d->spec_bg_error.clear();
+  d->spec_bg_state.store(1, std::memory_order_release);
+  d->spec_thread = std::thread([d, n_stages, arch]() {
+    std::vector<char> code;
+    int k = 0;
+    const cc_status s2 = spec_build(d->m, n_stages, arch, code, k);
+    if (s2 == CC_OK) {
+      d->spec_bg_code.swap(code);
+      d->spec_bg_stages = k;
+      d->spec_bg_state.store(2, std::memory_order_release);
+    } else {
+      d->spec_bg_error = cc_last_error();  // this thread's message
+      d->spec_bg_state.store(3, std::memory_order_release);
+    }
+  });
+  return CC_OK;
+}
+
 }  // namespace ccamd
 
 extern "C" {
@@ -1818,6 +1921,12 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
     CC_HIP(d->d_lbp2.upload(s2, d->stream));
     CC_HIP(hipStreamSynchronize(d->stream));
   }
+  // CCAMD_AUTO_SPECIALIZE=<stages>: build the specialised kernel in the background; detection starts on the table-driven
+  // kernel and switches over when the module is ready (no change to the calling code)
+  if (const char* e = std::getenv("CCAMD_AUTO_SPECIALIZE")) {
+    const int k = std::atoi(e);
+    if (k > 0 && d->m.max_nodes_per_tree == 1) (void)spec_start_background(d.get(), k);
+  }
   *out = d.release();
   return CC_OK;
 }
@@ -1838,6 +1947,9 @@ cc_status cc_detector_specialize(cc_detector* d, int n_stages) {
   if (!d) return set_error(CC_ERR_INVALID_ARG, "cc_detector_specialize: null detector");
   cc_status st = ensure_device(d->device);
   if (st != CC_OK) return st;
+  if (d->spec_thread.joinable()) d->spec_thread.join();  // a background build, if any, is superseded
+  d->spec_bg_state.store(0, std::memory_order_release);
+  d->spec_bg_code.clear();
   if (n_stages <= 0) {  // back to the table-driven kernel
     CC_HIP(hipStreamSynchronize(d->stream));
     if (d->spec_mod) (void)hipModuleUnload(d->spec_mod);
@@ -1846,68 +1958,31 @@ cc_status cc_detector_specialize(cc_detector* d, int n_stages) {
     d->spec_stages = 0;
     return CC_OK;
   }
-  if (d->m.max_nodes_per_tree > 1) return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: stump cascades only");
-  // bound the generated code: whole stages while the stump count stays under the budget (instruction cache)
-  int k = 0, stumps = 0;
-  int budget = 320;
-  if (const char* e = std::getenv("CCAMD_SPEC_BUDGET")) budget = std::max(1, std::atoi(e));  // tuning
-  while (k < (int)d->m.stage_ntrees.size() && k < n_stages && k < MAX_STAGES && (k == 0 || stumps + d->m.stage_ntrees[(size_t)k] <= budget))
-    stumps += d->m.stage_ntrees[(size_t)k++];
-  std::string src = kSpecPrelude;
-  src += "namespace ccamd {\n";
-  src += kEvalKernelSrc;
-  src += "\n}  // namespace ccamd\n";
-  const std::string marker = "//@@CC_SPEC_FUNCTIONS@@";
-  const size_t pos = src.find(marker);
-  if (pos == std::string::npos) return set_error(CC_ERR_HIP, "cc_detector_specialize: kernel source has no specialisation marker");
-  src.replace(pos, marker.size(), spec_stage_source(d->m, k));
-  hipDeviceProp_t prop;
-  CC_HIP(hipGetDeviceProperties(&prop, d->device));
-  std::string arch = prop.gcnArchName;
-  arch = arch.substr(0, arch.find(':'));
-  std::vector<char> code;
-  st = compile_specialised(src, arch, k, d->m.feature_type == CC_FEATURE_LBP, code);
+  std::string arch;
+  st = device_arch(d->device, arch);
   if (st != CC_OK) return st;
-  hipModule_t mod = nullptr;
-  hipFunction_t fn = nullptr;
-  CC_HIP(hipModuleLoadData(&mod, code.data()));
-  if (hipModuleGetFunction(&fn, mod, "k_eval_spec") != hipSuccess) {
-    (void)hipModuleUnload(mod);
-    return set_error(CC_ERR_HIP, "cc_detector_specialize: entry point not found in the compiled module");
-  }
-  if (d->lds > 64 * 1024) {  // same opt-in as the ahead-of-time kernels (cc_detector_create)
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      (void)hipModuleUnload(mod);
-      return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: %zu bytes of LDS per tile cannot be requested for a run-time module (%s)",
-                       d->lds, hipGetErrorString(e));
-    }
-  }
-  CC_HIP(hipStreamSynchronize(d->stream));
-  if (d->spec_mod) (void)hipModuleUnload(d->spec_mod);
-  d->spec_mod = mod;
-  d->spec_fn = fn;
-  d->spec_stages = k;
-  return CC_OK;
+  std::vector<char> code;
+  int k = 0;
+  st = spec_build(d->m, n_stages, arch, code, k);
+  if (st != CC_OK) return st;
+  return spec_install(d, code, k);
+}
+
+cc_status cc_detector_specialize_async(cc_detector* d, int n_stages) {
+  if (!d) return set_error(CC_ERR_INVALID_ARG, "cc_detector_specialize_async: null detector");
+  if (n_stages <= 0) return set_error(CC_ERR_INVALID_ARG, "cc_detector_specialize_async: n_stages must be positive");
+  cc_status st = ensure_device(d->device);
+  if (st != CC_OK) return st;
+  return spec_start_background(d, n_stages);
 }
 
 int cc_detector_specialized_stages(const cc_detector* d) { return d ? d->spec_stages : 0; }
 
 cc_status cc_cascade_compile_specialized(const cc_cascade* c, int n_stages, const char* arch, size_t* code_bytes) {
   if (!c || !arch || !code_bytes) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_compile_specialized: null argument");
-  if (c->m.max_nodes_per_tree > 1) return set_error(CC_ERR_UNSUPPORTED, "cc_cascade_compile_specialized: stump cascades only");
-  const int k = std::max(1, std::min<int>({n_stages, (int)c->m.stage_ntrees.size(), MAX_STAGES}));
-  std::string src = kSpecPrelude;
-  src += "namespace ccamd {\n";
-  src += kEvalKernelSrc;
-  src += "\n}  // namespace ccamd\n";
-  const std::string marker = "//@@CC_SPEC_FUNCTIONS@@";
-  const size_t pos = src.find(marker);
-  if (pos == std::string::npos) return set_error(CC_ERR_HIP, "cc_cascade_compile_specialized: kernel source has no specialisation marker");
-  src.replace(pos, marker.size(), spec_stage_source(c->m, k));
   std::vector<char> code;
-  const cc_status st = compile_specialised(src, arch, k, c->m.feature_type == CC_FEATURE_LBP, code);
+  int k = 0;
+  const cc_status st = spec_build(c->m, std::max(1, n_stages), arch, code, k);
   if (st != CC_OK) return st;
   *code_bytes = code.size();
   return CC_OK;

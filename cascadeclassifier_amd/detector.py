@@ -247,6 +247,11 @@ class CascadeClassifier:
         L.check(L.lib().cc_detector_specialize(self._detector(), int(n_stages)))
         return self.specialized_stages()
 
+    def specialize_async(self, n_stages: int = 4):
+        """Start the same build on a background thread; detection keeps using the table-driven kernel until a later call
+        finds the module ready (specialized_stages() then becomes non-zero)."""
+        L.check(L.lib().cc_detector_specialize_async(self._detector(), int(n_stages)))
+
     def specialized_stages(self) -> int:
         return L.lib().cc_detector_specialized_stages(self._detector())
 

@@ -185,6 +185,11 @@ CC_API cc_status cc_scale_plan(int win_w, int win_h, int width, int height, cons
  * effect (0 = none). cc_cascade_compile_specialized only compiles (no device needed; arch e.g. "gfx950") and returns
  * the code-object size: the build check of the generated source. */
 CC_API cc_status cc_detector_specialize(cc_detector* d, int n_stages);
+/* Same, without waiting: generation and compilation run on a background host thread while detection continues on the
+ * table-driven kernel; the first detection call after the build has finished loads the module and switches over
+ * (cc_detector_specialized_stages tells when). CCAMD_AUTO_SPECIALIZE=<stages> in the environment does this for every
+ * detector at creation, i.e. without any change to the calling code. */
+CC_API cc_status cc_detector_specialize_async(cc_detector* d, int n_stages);
 CC_API int cc_detector_specialized_stages(const cc_detector* d);
 CC_API cc_status cc_cascade_compile_specialized(const cc_cascade* c, int n_stages, const char* arch, size_t* code_bytes);
 

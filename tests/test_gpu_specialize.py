@@ -77,3 +77,35 @@ def test_specialise_refuses_what_it_does_not_cover(tmp_path):
     assert trees.load_from_string(cf.haar_tree_cascade(cal, with_tilted=False))
     with pytest.raises(cc.CascadeError, match="stump cascades only"):
         trees.specialize(2)
+
+
+def test_background_specialisation_switches_over(haar_xml, monkeypatch):
+    """cc_detector_specialize_async / CCAMD_AUTO_SPECIALIZE: detection runs on the table-driven kernel while a host thread
+    compiles, and a later call picks the module up; results identical before and after."""
+    import time
+    img = frame_natural(400, 300, 91)
+    want = orc.detect_multiscale(orc.load_cascade_xml(haar_xml), img, 1.1, 2, nthreads=8)
+    p = cc.CascadeClassifier(haar_xml)
+    p.specialize_async(2)
+    seen_plain = p.specialized_stages() == 0
+    deadline = time.time() + 120
+    while p.specialized_stages() == 0 and time.time() < deadline:
+        got = p.detectMultiScale(img, 1.1, 2)  # keeps working during the build
+        assert got.shape == want.shape and (got == want).all()
+        time.sleep(0.05)
+    assert seen_plain and p.specialized_stages() == 2
+    got = p.detectMultiScale(img, 1.1, 2)
+    assert got.shape == want.shape and (got == want).all()
+    # the environment switch does the same for a detector created without any call
+    monkeypatch.setenv("CCAMD_AUTO_SPECIALIZE", "2")
+    q = cc.CascadeClassifier(haar_xml)
+    deadline = time.time() + 120
+    while q.specialized_stages() == 0 and time.time() < deadline:
+        got = q.detectMultiScale(img, 1.1, 2)
+        assert got.shape == want.shape and (got == want).all()
+        time.sleep(0.02)
+    assert q.specialized_stages() == 2
+    del q  # destroying a detector joins its build thread
+    r = cc.CascadeClassifier(haar_xml)
+    r.specialize_async(3)
+    del r  # ... also while the build is still running
