@@ -783,6 +783,8 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
   n_stages = std::min<int>(n_stages, (int)m.stage_ntrees.size());
   std::string o;
   char buf[512];
+  int barrier_every = 2;  // stumps between scheduling barriers
+  if (const char* e = std::getenv("CCAMD_SPEC_BARRIER_EVERY")) barrier_every = std::max(1, std::atoi(e));  // tuning
   auto hexf = [&](float v) {
     snprintf(buf, sizeof(buf), "%af", (double)v);
     return std::string(buf);
@@ -853,7 +855,7 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
           } else {
             o += "      " + stump(d, m.stage_first[(size_t)s] + i) + "\n";
             // keep the scheduler from hoisting every LDS read of the stage to the top (register pressure -> spills)
-            if ((i & 1) == 1) o += "      __builtin_amdgcn_sched_barrier(0);\n";
+            if ((i + 1) % barrier_every == 0) o += "      __builtin_amdgcn_sched_barrier(0);\n";
           }
         }
         o += "    } break;\n";
