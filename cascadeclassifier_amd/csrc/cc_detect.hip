@@ -377,6 +377,7 @@ __global__ __launch_bounds__(256) void k_filter_candidates(const CandRaw* __rest
     o.y = __float2int_rn((float)(c.gy * S.ystep) * S.scale);
     o.w = S.win_w;
     o.h = S.win_h;
+    o.sum = c.sum;
     out[slot] = o;  // out has cand_cap entries; slot < n <= cand_cap
   }
 }
@@ -2074,6 +2075,38 @@ cc_status cc_detect_multiscale(cc_detector* d, const uint8_t* gray, int width, i
   cc_status st = cc_detect_batch(d, gray, 0, 1, width, height, row_stride, row_stride * (size_t)height, p, out, cap, offsets);
   if (st == CC_OK || st == CC_ERR_BUFFER_TOO_SMALL) *n = offsets[1];
   return st;
+}
+
+cc_status cc_detect_multiscale_levels(cc_detector* d, const uint8_t* gray, int width, int height, size_t row_stride,
+                                      const cc_detect_params* p, cc_rect* out, int32_t* reject_levels, double* level_weights,
+                                      int cap, int* n) {
+  cc_status st = check_frame_args(d, gray, 1, width, height, row_stride, p, "cc_detect_multiscale_levels");
+  if (st != CC_OK) return st;
+  if (!n || cap < 0 || (cap > 0 && (!out || !reject_levels || !level_weights)))
+    return set_error(CC_ERR_INVALID_ARG, "cc_detect_multiscale_levels: bad output buffers");
+  std::vector<CandOut> cands;
+  st = run_batch(d, gray, 0, 1, width, height, row_stride, row_stride * (size_t)height, p, true, false,
+                 [&](int, int, std::vector<CandOut>& c) { cands.insert(cands.end(), c.begin(), c.end()); });
+  if (st != CC_OK) return st;
+  sort_candidates(cands);  // OpenCV's single-threaded order
+  std::vector<cc_rect> rects;
+  std::vector<int> levels;
+  std::vector<double> weights;
+  const int nstages = (int)d->m.stage_ntrees.size();
+  for (const CandOut& c : cands) {  // only windows that passed every stage are reported: level = number of stages
+    rects.push_back(cc_rect{c.x, c.y, c.w, c.h});
+    levels.push_back(nstages);
+    weights.push_back(c.sum);
+  }
+  group_rectangles(rects, p->min_neighbors, 0.2, &levels, &weights);
+  *n = (int)rects.size();
+  for (int i = 0; i < (int)rects.size() && i < cap; i++) {
+    out[i] = rects[(size_t)i];
+    reject_levels[i] = levels[(size_t)i];
+    level_weights[i] = weights[(size_t)i];
+  }
+  if ((int)rects.size() > cap) return set_error(CC_ERR_BUFFER_TOO_SMALL, "cc_detect_multiscale_levels: %zu rectangles, capacity %d", rects.size(), cap);
+  return CC_OK;
 }
 
 cc_status cc_detect_raw(cc_detector* d, const uint8_t* gray, int width, int height, size_t row_stride, const cc_detect_params* p,

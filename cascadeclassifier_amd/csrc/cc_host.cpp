@@ -104,9 +104,10 @@ void linear_exact_taps(int src, int dst, AxisTaps& t) {
 
 // cv::groupRectangles. Classes are the connected components of the SimilarRects graph, labelled in
 // order of first appearance, which is what cv::partition yields.
-void group_rectangles(std::vector<cc_rect>& rects, int group_threshold, double eps) {
+void group_rectangles(std::vector<cc_rect>& rects, int group_threshold, double eps, std::vector<int>* levels,
+                      std::vector<double>* level_weights) {
   const int n = (int)rects.size();
-  if (group_threshold <= 0 || n == 0) return;
+  if (group_threshold <= 0 || n == 0) return;  // (with both vectors given, upstream leaves them untouched here as well)
   std::vector<int> parent(n), rank_(n, 0);
   std::iota(parent.begin(), parent.end(), 0);
   auto find = [&](int a) {
@@ -164,6 +165,19 @@ void group_rectangles(std::vector<cc_rect>& rects, int group_threshold, double e
     const float s = 1.f / cnt[i];
     acc[i] = cc_rect{rnd_f(acc[i].x * s), rnd_f(acc[i].y * s), rnd_f(acc[i].width * s), rnd_f(acc[i].height * s)};
   }
+  // outputRejectLevels variant: per class the highest level among its members and, among those, the largest weight
+  std::vector<int> cls_level(nclasses, 0), out_levels;
+  std::vector<double> cls_weight(nclasses, DBL_MIN), out_weights;
+  const bool with_levels = levels && level_weights && !levels->empty() && !level_weights->empty();
+  if (with_levels)
+    for (int i = 0; i < n; i++) {
+      const int c = label[i];
+      if ((*levels)[(size_t)i] > cls_level[c]) {
+        cls_level[c] = (*levels)[(size_t)i];
+        cls_weight[c] = (*level_weights)[(size_t)i];
+      } else if ((*levels)[(size_t)i] == cls_level[c] && (*level_weights)[(size_t)i] > cls_weight[c])
+        cls_weight[c] = (*level_weights)[(size_t)i];
+    }
   std::vector<cc_rect> out;
   for (int i = 0; i < nclasses; i++) {
     const cc_rect r1 = acc[i];
@@ -179,9 +193,15 @@ void group_rectangles(std::vector<cc_rect>& rects, int group_threshold, double e
           r1.y + r1.height <= r2.y + r2.height + dy && (n2 > std::max(3, n1) || n1 < 3))
         break;
     }
-    if (j == nclasses) out.push_back(r1);
+    if (j == nclasses) {
+      out.push_back(r1);
+      out_levels.push_back(with_levels ? cls_level[i] : n1);  // "useDefaultWeights": the class size
+      out_weights.push_back(cls_weight[i]);
+    }
   }
   rects.swap(out);
+  if (levels) levels->swap(out_levels);
+  if (level_weights) level_weights->swap(out_weights);
 }
 
 // Haar catalog in the reference's order (traincascade/lib/src/haarfeatures.cpp:127-251); the feature index is part of

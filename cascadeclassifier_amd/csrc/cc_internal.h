@@ -78,7 +78,9 @@ struct AxisTaps {
 };
 void linear_exact_taps(int src, int dst, AxisTaps& t);
 
-void group_rectangles(std::vector<cc_rect>& rects, int group_threshold, double eps);
+// levels / level_weights (optional, one per rectangle): the outputRejectLevels overload of cv::groupRectangles
+void group_rectangles(std::vector<cc_rect>& rects, int group_threshold, double eps, std::vector<int>* levels = nullptr,
+                      std::vector<double>* level_weights = nullptr);
 
 // ---- catalogs (training side) -------------------------------------------------------------------
 void haar_catalog(int W, int H, int mode, std::vector<HaarFeature>& out);

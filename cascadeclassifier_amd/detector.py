@@ -210,6 +210,28 @@ class CascadeClassifier:
         fs = frame_stride or rs * h
         L.check(L.lib().cc_detect_batch_device_only(self._detector(), C.c_void_p(device_ptr), 1, n, w, h, rs, fs, C.byref(p)))
 
+    def detectMultiScale3(self, image, scaleFactor=1.1, minNeighbors=3, flags=0, minSize=None, maxSize=None, outputRejectLevels=True):
+        """cv2.CascadeClassifier.detectMultiScale3: (rects (n, 4) int32, rejectLevels (n,) int32, levelWeights (n,) float64)."""
+        if not outputRejectLevels:
+            r = self.detectMultiScale(image, scaleFactor, minNeighbors, flags, minSize, maxSize)
+            return r, np.zeros(0, np.int32), np.zeros(0, np.float64)
+        image = np.ascontiguousarray(image, np.uint8)
+        h, w = image.shape
+        p = _params(scaleFactor, minNeighbors, minSize, maxSize)
+        cap = 1024
+        while True:
+            rects = np.zeros((cap, 4), np.int32)
+            levels = np.zeros(cap, np.int32)
+            weights = np.zeros(cap, np.float64)
+            n = C.c_int(0)
+            st = L.lib().cc_detect_multiscale_levels(self._detector(), _vp(image), w, h, w, C.byref(p), _vp(rects), _vp(levels), _vp(weights),
+                                                     cap, C.byref(n))
+            if st == L.CC_ERR_BUFFER_TOO_SMALL:
+                cap = n.value
+                continue
+            L.check(st)
+            return rects[:n.value].copy(), levels[:n.value].copy(), weights[:n.value].copy()
+
     def detect_raw(self, image, scaleFactor=1.1, minSize=None, maxSize=None) -> np.ndarray:
         image = np.ascontiguousarray(image, np.uint8)
         h, w = image.shape

@@ -152,6 +152,15 @@ CC_API cc_status cc_detect_batch_device_only(cc_detector* d, const uint8_t* fram
                                              int width, int height, size_t row_stride, size_t frame_stride,
                                              const cc_detect_params* p);
 
+/* The outputRejectLevels overload of cv::CascadeClassifier::detectMultiScale (objects, rejectLevels, levelWeights,
+ * ..., outputRejectLevels = true; OpenCV 4.6.0 objdetect, no call site in the reference: SURVEY.md 8f-4). Windows that
+ * pass every stage are reported with level = number of stages and weight = the stage sum of the last stage; the
+ * grouping keeps, per class, the highest level and among its members the largest weight (cv::groupRectangles with
+ * weights). Parity unpinned like the rest of the detection side. out / reject_levels / level_weights hold cap entries. */
+CC_API cc_status cc_detect_multiscale_levels(cc_detector* d, const uint8_t* gray, int width, int height, size_t row_stride,
+                                             const cc_detect_params* p, cc_rect* out, int32_t* reject_levels,
+                                             double* level_weights, int cap, int* n);
+
 /* Ungrouped candidates of one frame, as int32[7] = {scale_idx, gx, gy, x, y, w, h}, sorted (scale, gy, gx). */
 CC_API cc_status cc_detect_raw(cc_detector* d, const uint8_t* gray, int width, int height, size_t row_stride,
                                const cc_detect_params* p, int32_t* cand, int cap, int* n);

@@ -689,9 +689,19 @@ ORC_API int orc_detect_raw(const OrcCascade* c, const uint8_t* img, int w, int h
 
 // cv::groupRectangles(rectList, groupThreshold, eps). rects: n x {x,y,w,h}. Output written to
 // out (cap rects), returns count. Output order = class-label order of cv::partition for the given input order.
-ORC_API int orc_group_rectangles(const int32_t* rects, int n, int groupThreshold, double eps, int32_t* out, int cap) {
+// levels / level_weights (both NULL or both n long): cv::groupRectangles(rectList, rejectLevels, levelWeights,
+// groupThreshold, eps), the grouping of detectMultiScale's outputRejectLevels overload: per class the highest level and,
+// among the members at that level, the largest weight; out_levels / out_weights receive them per kept rectangle.
+static int group_rectangles_impl(const int32_t* rects, int n, int groupThreshold, double eps, int32_t* out, int cap,
+                                 const int32_t* levels, const double* level_weights, int32_t* out_levels, double* out_weights) {
   if (groupThreshold <= 0 || n == 0) {
-    for (int i = 0; i < n && i < cap; i++) std::memcpy(out + 4 * i, rects + 4 * i, 16);
+    for (int i = 0; i < n && i < cap; i++) {
+      std::memcpy(out + 4 * i, rects + 4 * i, 16);
+      if (levels) {
+        out_levels[i] = levels[i];
+        out_weights[i] = level_weights[i];
+      }
+    }
     return n;
   }
   auto similar = [&](const int32_t* a, const int32_t* b) {
@@ -730,6 +740,17 @@ ORC_API int orc_group_rectangles(const int32_t* rects, int n, int groupThreshold
     float s = 1.f / rw[i];
     for (int k = 0; k < 4; k++) rr[4 * i + k] = cv_round_f(rr[4 * i + k] * s);
   }
+  std::vector<int> rejectLevels(nclasses, 0);
+  std::vector<double> rejectWeights(nclasses, 2.2250738585072014e-308 /* DBL_MIN */);
+  if (levels)
+    for (int i = 0; i < n; i++) {
+      int cls = label[i];
+      if (levels[i] > rejectLevels[cls]) {
+        rejectLevels[cls] = levels[i];
+        rejectWeights[cls] = level_weights[i];
+      } else if (levels[i] == rejectLevels[cls] && level_weights[i] > rejectWeights[cls])
+        rejectWeights[cls] = level_weights[i];
+    }
   int m = 0;
   for (int i = 0; i < nclasses; i++) {
     const int32_t* r1 = &rr[4 * i];
@@ -746,11 +767,27 @@ ORC_API int orc_group_rectangles(const int32_t* rects, int n, int groupThreshold
         break;
     }
     if (j == nclasses) {
-      if (m < cap) std::memcpy(out + 4 * m, r1, 16);
+      if (m < cap) {
+        std::memcpy(out + 4 * m, r1, 16);
+        if (levels) {
+          out_levels[m] = rejectLevels[i];
+          out_weights[m] = rejectWeights[i];
+        }
+      }
       m++;
     }
   }
   return m;
+}
+
+ORC_API int orc_group_rectangles(const int32_t* rects, int n, int groupThreshold, double eps, int32_t* out, int cap) {
+  return group_rectangles_impl(rects, n, groupThreshold, eps, out, cap, nullptr, nullptr, nullptr, nullptr);
+}
+
+ORC_API int orc_group_rectangles_levels(const int32_t* rects, const int32_t* levels, const double* level_weights, int n,
+                                        int groupThreshold, double eps, int32_t* out, int32_t* out_levels, double* out_weights,
+                                        int cap) {
+  return group_rectangles_impl(rects, n, groupThreshold, eps, out, cap, levels, level_weights, out_levels, out_weights);
 }
 
 // detectMultiScale = raw candidates + groupRectangles(minNeighbors, eps = 0.2).

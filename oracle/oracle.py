@@ -331,6 +331,26 @@ def detect_multiscale(c: Cascade, img: np.ndarray, scale_factor=1.1, min_neighbo
     return group_rectangles(raw.candidates[:, 3:7], min_neighbors, 0.2)
 
 
+def detect_multiscale_levels(c: Cascade, img: np.ndarray, scale_factor=1.1, min_neighbors=3, min_size=(0, 0), max_size=(0, 0), nthreads=1):
+    """detectMultiScale(..., outputRejectLevels=true): accepted windows carry level = number of stages and weight = the last
+    stage's sum (runAt's gypWeight); grouped with cv::groupRectangles(rects, levels, weights, ...)."""
+    raw = detect_raw(c, img, scale_factor, min_size, max_size, nthreads, full=True)
+    h, w = np.asarray(img).shape
+    sc = scales(c.win_w, c.win_h, w, h, scale_factor, min_size, max_size)
+    first = np.concatenate([[0], np.cumsum(sc["nx"].astype(np.int64) * sc["ny"])])
+    cand = raw.candidates
+    n = len(cand)
+    idx = first[cand[:, 0]] + cand[:, 2].astype(np.int64) * sc["nx"][cand[:, 0]] + cand[:, 1] if n else np.zeros(0, np.int64)
+    weights = np.ascontiguousarray(raw.sums[idx], np.float64)
+    levels = np.full(n, c.nstages, np.int32)
+    rects = np.ascontiguousarray(cand[:, 3:7], np.int32)
+    out = np.zeros((max(n, 1), 4), np.int32)
+    ol = np.zeros(max(n, 1), np.int32)
+    ow = np.zeros(max(n, 1), np.float64)
+    m = lib().orc_group_rectangles_levels(_p(rects), _p(levels), _p(weights), n, min_neighbors, C.c_double(0.2), _p(out), _p(ol), _p(ow), max(n, 1))
+    return out[:m], ol[:m], ow[:m]
+
+
 def train_predict(c: Cascade, s, t, nf, si, W, H) -> int:
     cs = c.c_struct()
     return int(lib().orc_train_predict(C.byref(cs), _p(s), _p(t), _p(nf), si, W, H))

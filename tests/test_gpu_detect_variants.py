@@ -85,3 +85,27 @@ def test_windows_other_than_24x24(tmp_path, W, H):
     xml = cf.lbp_stump_cascade(W, H)
     n = _check(xml, str(tmp_path), [frame_natural(400, 300, 51), frame_natural(W + 3, H + 40, 52)], sfs=(1.1, 1.5))
     assert n > 0
+
+
+@pytest.mark.parametrize("which", ["haar", "lbp", "haar_specialised"])
+def test_output_reject_levels_overload(which, haar_xml, lbp_xml):
+    """detectMultiScale(objects, rejectLevels, levelWeights, ..., outputRejectLevels=true): rectangles, levels (= number of
+    stages for every accepted window) and weights (the last stage's sum, the largest one per group) against the oracle."""
+    xml = lbp_xml if which == "lbp" else haar_xml
+    o = orc.load_cascade_xml(xml)
+    p = cc.CascadeClassifier(xml)
+    if which == "haar_specialised":
+        p.specialize(7)
+    total = 0
+    for img, sf, mn in ((frame_natural(640, 360, 11), 1.1, 2), (frame_natural(400, 300, 12), 1.2, 0), (frame_uniform(200, 150, 13), 1.1, 1)):
+        rects, levels, weights = p.detectMultiScale3(img, sf, mn, outputRejectLevels=True)
+        wr, wl, ww = orc.detect_multiscale_levels(o, img, sf, mn, nthreads=8)
+        key_g = np.lexsort((weights, rects[:, 3], rects[:, 2], rects[:, 1], rects[:, 0])) if len(rects) else np.zeros(0, int)
+        key_w = np.lexsort((ww, wr[:, 3], wr[:, 2], wr[:, 1], wr[:, 0])) if len(wr) else np.zeros(0, int)
+        assert rects.shape == wr.shape and (rects[key_g] == wr[key_w]).all()
+        assert (levels[key_g] == wl[key_w]).all() and (levels == o.nstages).all()
+        assert (weights[key_g] == ww[key_w]).all()  # bit-exact stage sums
+        plain = p.detectMultiScale(img, sf, mn)
+        assert plain.shape == rects.shape  # same rectangles as the ordinary overload
+        total += len(rects)
+    assert total > 0
