@@ -161,6 +161,10 @@ class CascadeClassifier {
   // image: CV_8UC1. Same defaults as cv::CascadeClassifier::detectMultiScale.
   void detectMultiScale(const cv::Mat& image, std::vector<cv::Rect>& objects, double scaleFactor = 1.1, int minNeighbors = 3,
                         int flags = 0, cv::Size minSize = cv::Size(), cv::Size maxSize = cv::Size());
+  // the outputRejectLevels overload (levels = number of stages, weights = the last stage's sum of the group's best window)
+  void detectMultiScale(const cv::Mat& image, std::vector<cv::Rect>& objects, std::vector<int>& rejectLevels,
+                        std::vector<double>& levelWeights, double scaleFactor = 1.1, int minNeighbors = 3, int flags = 0,
+                        cv::Size minSize = cv::Size(), cv::Size maxSize = cv::Size(), bool outputRejectLevels = false);
   cv::Size getOriginalWindowSize() const;
   // Optional, once per loaded cascade: compile its first stages into the cascade kernel (cc_detector_specialize).
   // Returns the number of stages in effect; 0 if the cascade or the installation does not support it (lastError()).

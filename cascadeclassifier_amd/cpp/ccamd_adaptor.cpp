@@ -435,4 +435,43 @@ void CascadeClassifier::detectMultiScale(const cv::Mat& image, std::vector<cv::R
   for (int i = 0; i < n; i++) objects.emplace_back(out[i].x, out[i].y, out[i].width, out[i].height);
 }
 
+void CascadeClassifier::detectMultiScale(const cv::Mat& image, std::vector<cv::Rect>& objects, std::vector<int>& rejectLevels,
+                                         std::vector<double>& levelWeights, double scaleFactor, int minNeighbors, int flags,
+                                         cv::Size minSize, cv::Size maxSize, bool outputRejectLevels) {
+  rejectLevels.clear();
+  levelWeights.clear();
+  if (!outputRejectLevels) {
+    detectMultiScale(image, objects, scaleFactor, minNeighbors, flags, minSize, maxSize);
+    return;
+  }
+  objects.clear();
+  CV_Assert(scaleFactor > 1 && image.type() == CV_8UC1);
+  if (empty()) return;
+  if (!d) check(cc_detector_create(c, device, 1, &d), "CascadeClassifier::detectMultiScale");
+  cc_detect_params p;
+  p.scale_factor = scaleFactor;
+  p.min_neighbors = minNeighbors;
+  p.min_w = minSize.width;
+  p.min_h = minSize.height;
+  p.max_w = maxSize.width;
+  p.max_h = maxSize.height;
+  std::vector<cc_rect> out(1024);
+  std::vector<int32_t> lv(1024);
+  std::vector<double> wt(1024);
+  int n = 0;
+  cc_status st = cc_detect_multiscale_levels(d, image.data, image.cols, image.rows, image.step, &p, out.data(), lv.data(), wt.data(), (int)out.size(), &n);
+  if (st == CC_ERR_BUFFER_TOO_SMALL) {
+    out.resize((size_t)n);
+    lv.resize((size_t)n);
+    wt.resize((size_t)n);
+    st = cc_detect_multiscale_levels(d, image.data, image.cols, image.rows, image.step, &p, out.data(), lv.data(), wt.data(), (int)out.size(), &n);
+  }
+  check(st, "CascadeClassifier::detectMultiScale");
+  for (int i = 0; i < n; i++) {
+    objects.emplace_back(out[i].x, out[i].y, out[i].width, out[i].height);
+    rejectLevels.push_back(lv[i]);
+    levelWeights.push_back(wt[i]);
+  }
+}
+
 }  // namespace ccamd

@@ -234,6 +234,16 @@ int main(int argc, char** argv) {
     CHECK(objects.empty());
     cascade.detectMultiScale(gray, objects, 1.1, 0);
     std::printf("        ungrouped candidates on the synthetic pattern: %zu\n", objects.size());
+    {
+      std::vector<cv::Rect> lobj;
+      std::vector<int> levels;
+      std::vector<double> weights;
+      cascade.detectMultiScale(gray, lobj, levels, weights, 1.1, 0, 0, cv::Size(), cv::Size(), true);
+      CHECK(lobj.size() == objects.size() && levels.size() == lobj.size() && weights.size() == lobj.size());
+      bool all_last = true;
+      for (int l : levels) all_last = all_last && l == 25;  // accepted windows passed all 25 stages
+      CHECK(all_last);
+    }
     const int spec = cascade.specialize(3);  // 0 where libhiprtc is missing; results must not change either way
     std::vector<cv::Rect> again;
     cascade.detectMultiScale(gray, again, 1.1, 0);
