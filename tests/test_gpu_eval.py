@@ -261,3 +261,33 @@ def test_sorted_index_precalc(ftype):
         assert (want[r] == 0).sum() >= 2 and np.signbit(want[r][want[r] == 0]).any()
     _, idx32 = e.calc_batch_sorted(a, a + 5, idx_bytes=4)
     assert idx32.dtype == np.int32 and (idx32 == idx[:5]).all()
+
+
+def test_operator_call_is_safe_for_concurrent_callers():
+    """The reference calls operator() from cv::parallel_for_ workers (o_cvcascadeboosttraindata.cpp:586-594): concurrent
+    calc / calc_batch on one evaluator must give the same values as serial calls."""
+    import threading
+    rng = np.random.default_rng(5)
+    imgs = rng.integers(0, 256, (48, 24, 24), dtype=np.uint8)
+    e = _mk(ev.HAAR, ev.BASIC, 48)
+    e.setImages(imgs, np.zeros(48, np.uint8))
+    want = e.calc_batch(1000, 1400)
+    errors = []
+
+    def work(t):
+        try:
+            for rep in range(6):
+                f0 = 1000 + 50 * ((t + rep) % 8)
+                got = e.calc_batch(f0, f0 + 50)
+                assert (got.view(np.uint32) == want[f0 - 1000:f0 - 950].view(np.uint32)).all()
+                fi, si = 1000 + (37 * t + rep) % 400, (11 * t + rep) % 48
+                assert np.float32(e(fi, si)).view(np.uint32) == want[fi - 1000, si].view(np.uint32)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
