@@ -1435,26 +1435,45 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       CC_HIP(hipStreamSynchronize(d->front_stream));
       d->eval_pending[0] = d->eval_pending[1] = false;
     }
+    bool launched = false;
     if (P->graph_exec && P->graph_key == key_now()) {
       CC_HIP(hipGraphLaunch(P->graph_exec, d->stream));
+      launched = true;
     } else if (P->graph_warm) {
       if (P->graph_exec) (void)hipGraphExecDestroy(P->graph_exec);
       P->graph_exec = nullptr;
       hipGraph_t graph = nullptr;
-      CC_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal));
-      const cc_status s2 = body();
-      const hipError_t ce = hipStreamEndCapture(d->stream, &graph);
-      if (s2 != CC_OK) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return s2;
+      // Relaxed mode: this thread's stream-ordered calls are captured, nobody's legacy-stream calls are policed (other
+      // host threads may be inside synchronous copies of their own handles; under the stricter modes HIP fails those
+      // calls and invalidates this capture). One capture at a time per process; if a capture does not come out, the
+      // detector simply stops using graphs.
+      static std::mutex capture_mu;
+      hipError_t ce = hipSuccess, ie = hipSuccess;
+      cc_status s2 = CC_OK;
+      {
+        std::lock_guard<std::mutex> capture_lock(capture_mu);
+        ce = hipStreamBeginCapture(d->stream, hipStreamCaptureModeRelaxed);
+        if (ce == hipSuccess) {
+          s2 = body();
+          ce = hipStreamEndCapture(d->stream, &graph);
+        }
       }
-      CC_HIP(ce);
-      const hipError_t ie = hipGraphInstantiate(&P->graph_exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      CC_HIP(ie);
-      P->graph_key = key_now();
-      CC_HIP(hipGraphLaunch(P->graph_exec, d->stream));
-    } else {
+      if (ce == hipSuccess && s2 == CC_OK && graph) ie = hipGraphInstantiate(&P->graph_exec, graph, nullptr, nullptr, 0);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (ce != hipSuccess || s2 != CC_OK || ie != hipSuccess || !P->graph_exec) {
+        if (std::getenv("CCAMD_TIMING"))
+          std::fprintf(stderr, "[ccamd] graph capture failed (begin/end: %s, body status %d, instantiate: %s): using ordinary launches\n",
+                       hipGetErrorString(ce), (int)s2, hipGetErrorString(ie));
+        (void)hipGetLastError();
+        P->graph_exec = nullptr;
+        d->use_graph = 0;  // ordinary launches from now on (this call included)
+      } else {
+        P->graph_key = key_now();
+        CC_HIP(hipGraphLaunch(P->graph_exec, d->stream));
+        launched = true;
+      }
+    }
+    if (!launched) {
       stt = body();
       if (stt != CC_OK) return stt;
       P->graph_warm = true;  // every buffer now has its size: the next call can be captured
@@ -1463,7 +1482,10 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     const int raw = d->h_counts[0], kept = d->h_counts[1];
     if (raw <= d->cand_cap) {
       std::vector<CandOut> got((size_t)kept);
-      if (kept > 0) CC_HIP(hipMemcpy(got.data(), d->d_out[0].p, (size_t)kept * sizeof(CandOut), hipMemcpyDeviceToHost));
+      if (kept > 0) {
+        CC_HIP(hipMemcpyAsync(got.data(), d->d_out[0].p, (size_t)kept * sizeof(CandOut), hipMemcpyDeviceToHost, d->stream));
+        CC_HIP(hipStreamSynchronize(d->stream));
+      }
       consume(0, 1, got);
       return CC_OK;
     }
@@ -1695,6 +1717,18 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
     if (FILE* f = std::fopen(dump, "w")) {
       std::fwrite(src.data(), 1, src.size(), f);
       std::fclose(f);
+    }
+  }
+  // One compilation at a time per process: builds are rare and seconds long, the compiler stack underneath hiprtc is not
+  // worth trusting with concurrent invocations, and a second thread asking for the same code waits here and then finds it.
+  static std::mutex compile_mu;
+  std::lock_guard<std::mutex> compile_lock(compile_mu);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+      code = it->second;
+      return CC_OK;
     }
   }
   const HipRtcApi& rtc = hiprtc_api();
