@@ -3,7 +3,7 @@
 // bottom (cc_detector). Replaces cv::CascadeClassifier::detectMultiScale as called by the reference's detection tool
 // (tools/detection/Cpp/main.cpp:42-45); behaviour follows SURVEY.md Appendix A.
 //
-// Data layout in HBM (per frame slot f of a batch; all slabs are sized for max_batch frames):
+// Data layout in HBM (per frame slot f of a pass; all slabs are sized for the largest pass, at most max_batch frames):
 //   pyramid  u8   : scale s at pyr + f*pyr_frame_bytes + img_ofs[s], row pitch pitch8[s] (multiple of 4)
 //   integral i32  : sum   at integ + (f*nchan + 0)*int_frame_elems + int_ofs[s], (h+1) rows x pitchI[s] (multiple of 4)
 //                   sqsum at integ + (f*nchan + 1)*int_frame_elems + int_ofs[s]   (Haar only; u32 wrap-around). With an even
@@ -598,6 +598,7 @@ struct cc_detector {
   Cascade m;
   int device = 0;
   int max_batch = 1;
+  int pass_capacity = 1;  // frames the per-pass workspace is sized for: the largest pass seen so far (<= max_batch)
   hipStream_t own_stream = nullptr, stream = nullptr;
   // cascade tables on the device (one per tile layout)
   DevBuf<int> d_stage_ntrees, d_stage_first;
@@ -1258,11 +1259,11 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   if (ns == 0 || nf == 0) return CC_OK;
   // even window sizes: the variance rectangle's corners of step-2 scales sit on odd rows and odd columns only
   const int sq_compact = (haar && d->m.win_w % 2 == 0 && d->m.win_h % 2 == 0 && !d->full_sqsum) ? 1 : 0;
-  CC_HIP(d->d_pyr.ensure(P->pyr_frame_bytes * (size_t)d->max_batch));
-  CC_HIP(d->d_integ[slot].ensure(P->int_frame_elems * (size_t)nchan * (size_t)d->max_batch));
-  CC_HIP(d->d_hbuf.ensure(std::max<size_t>(P->h_frame_elems * (size_t)nchan * (size_t)d->max_batch, 4)));
-  if (tilt) CC_HIP(d->d_diag.ensure(P->int_frame_elems * 2 * (size_t)d->max_batch));
-  CC_HIP(d->d_masks.ensure(std::max<size_t>(P->mask_frame_words * (size_t)d->max_batch, 1)));
+  CC_HIP(d->d_pyr.ensure(P->pyr_frame_bytes * (size_t)d->pass_capacity));
+  CC_HIP(d->d_integ[slot].ensure(P->int_frame_elems * (size_t)nchan * (size_t)d->pass_capacity));
+  CC_HIP(d->d_hbuf.ensure(std::max<size_t>(P->h_frame_elems * (size_t)nchan * (size_t)d->pass_capacity, 4)));
+  if (tilt) CC_HIP(d->d_diag.ensure(P->int_frame_elems * 2 * (size_t)d->pass_capacity));
+  CC_HIP(d->d_masks.ensure(std::max<size_t>(P->mask_frame_words * (size_t)d->pass_capacity, 1)));
   if (d->cand_cap == 0) d->cand_cap = 1 << 18;
   CC_HIP(d->d_cands.ensure((size_t)d->cand_cap));
   CC_HIP(d->d_out[slot].ensure((size_t)d->cand_cap));
@@ -1418,7 +1419,7 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       d->h_frame_bytes = fs;
     }
     for (int y = 0; y < height; y++) std::memcpy(d->h_frame + (size_t)y * rs, frames + (size_t)y * row_stride, (size_t)width);
-    CC_HIP(d->d_frames.ensure(fs * (size_t)d->max_batch * 2));
+    CC_HIP(d->d_frames.ensure(fs * (size_t)d->pass_capacity * 2));
     auto body = [&]() -> cc_status {
       CC_HIP(hipMemcpyAsync(d->d_frames.p, d->h_frame, fs, hipMemcpyHostToDevice, d->stream));
       cc_status s2 = run_device_pass(d, P, d->d_frames.p, 1, rs, fs, false, 0, true);
@@ -1528,6 +1529,7 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     }
     sizes.swap(fixed);
   }
+  for (int v : sizes) d->pass_capacity = std::max(d->pass_capacity, v);  // the workspace only ever grows
   struct Pass {
     int f0, nf, slot;
     const uint8_t* dptr;
@@ -1577,8 +1579,8 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     } else {  // staging area is double-buffered like the results
       ps.rs = (size_t)align_up(width, 4);
       ps.fs = ps.rs * (size_t)height;
-      CC_HIP(d->d_frames.ensure(ps.fs * (size_t)d->max_batch * 2));
-      uint8_t* stage = d->d_frames.p + (size_t)slot * ps.fs * (size_t)d->max_batch;
+      CC_HIP(d->d_frames.ensure(ps.fs * (size_t)d->pass_capacity * 2));
+      uint8_t* stage = d->d_frames.p + (size_t)slot * ps.fs * (size_t)d->pass_capacity;
       for (int f = 0; f < ps.nf; f++)
         CC_HIP(hipMemcpy2DAsync(stage + (size_t)f * ps.fs, ps.rs, frames + (size_t)(f0 + f) * frame_stride, row_stride,
                                 (size_t)width, (size_t)height, hipMemcpyHostToDevice, front));
