@@ -51,6 +51,36 @@ def usable_cores():
     return n
 
 
+def spawn_ranks(n):
+    """Starts n copies of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, 127.0.0.1 rendezvous on a free port) and
+    waits for them. Returns the first non-zero exit status, or 0. If one rank dies the others are terminated, so a
+    failed rendezvous cannot hang the caller."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    status = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +102,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process never touches the GPU; it starts one rank per GPU as child
+        # processes (the env contract of torch.distributed.run) and exits with their status. Rank 0 prints the JSON line.
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -243,6 +278,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if out.get("cpu_baseline", {}).get("rectangles_identical_to_gpu") is False:
+        sys.exit("bench.py: GPU rectangles differ from the CPU oracle on the baseline sample: the number above is invalid")
 
 
 if __name__ == "__main__":

@@ -770,9 +770,59 @@ static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) 
   }
 }
 
-// Source text of spec_stage<1|2> and spec_stage_part<1|2> for the first n_stages stages: every stump becomes
+// Source text of spec_stage<1|2> (and spec_stage0_x2<1|2>) for the first n_stages stages: every stump becomes
 // straight-line code whose LDS offsets, weights, threshold and leaf values are literals (hex floats, exact). The
 // expression is the one of stump_vote(), term by term, so results are bit-identical to the table-driven path.
+//
+// The code is software-pipelined by construction: the LDS reads of stump i + D are issued before stump i is computed,
+// and scheduling barriers pin that order (left alone, the compiler emits read, wait, compute per stump and every
+// wavefront spends most of its time waiting for the LDS round trip). One copy of a stage serves the whole-stage call and
+// the stump-split calls: the stage is cut into EVAL_WAVES contiguous parts, a call evaluates parts [p_lo, p_hi) and only
+// its first part runs the prologue that issues the first D stumps' reads (a part's tail prefetches into the next part,
+// so consecutive parts run without a pipeline drain).
+struct SpecStump {
+  std::string loads;    // statements "x = b[..];" (variables are declared by the caller)
+  std::string decls;    // declarations of those variables
+  std::string compute;  // statement adding the stump's vote to `acc`
+};
+
+static int spec_prefetch_depth() {
+  int d = 2;
+  if (const char* e = std::getenv("CCAMD_SPEC_PREFETCH")) d = std::max(0, std::min(4, std::atoi(e)));  // tuning
+  return d;
+}
+
+// Emits the body of one stage from per-stump pieces (see above). `suffixes` = one accumulator / window per entry.
+static void spec_emit_stage(std::string& o, const std::vector<SpecStump>& st, int depth, bool parts) {
+  const int nt = (int)st.size();
+  static const char* kSB = "      __builtin_amdgcn_sched_barrier(0);\n";
+  for (const SpecStump& t : st) o += "      " + t.decls + "\n";
+  const int P = parts ? EVAL_WAVES : 1;
+  char buf[128];
+  for (int k = 0; k < P; k++) {
+    const int e0 = (int)((long long)k * nt / P), e1 = (int)((long long)(k + 1) * nt / P);
+    if (e0 == e1) continue;
+    if (parts)
+      snprintf(buf, sizeof(buf), "      if (p_lo == %d) {\n", k);
+    else
+      snprintf(buf, sizeof(buf), "      {\n");
+    o += buf;
+    for (int i = e0; i < std::min(e0 + depth, nt); i++) o += "      " + st[(size_t)i].loads + "\n" + kSB;
+    o += "      }\n";
+    if (parts) {
+      snprintf(buf, sizeof(buf), "      if (p_lo <= %d && %d < p_hi) {\n", k, k);
+      o += buf;
+    } else
+      o += "      {\n";
+    for (int i = e0; i < e1; i++) {
+      if (depth > 0 && i + depth < nt) o += "      " + st[(size_t)(i + depth)].loads + "\n" + kSB;
+      if (depth == 0) o += "      " + st[(size_t)i].loads + "\n";
+      o += "      " + st[(size_t)i].compute + "\n" + kSB;
+    }
+    o += "      }\n";
+  }
+}
+
 static std::string spec_stage_source_lbp(const Cascade& m, int n_stages);
 template <int STEP>
 static void build_lbp_stumps(const Cascade& m, std::vector<LbpStumpDev>& out);
@@ -783,19 +833,19 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
   build_haar_stumps<1>(m, t[0]);
   build_haar_stumps<2>(m, t[1]);
   n_stages = std::min<int>(n_stages, (int)m.stage_ntrees.size());
+  const int depth = spec_prefetch_depth();
   std::string o;
   char buf[512];
-  int barrier_every = 2;  // stumps between scheduling barriers
-  if (const char* e = std::getenv("CCAMD_SPEC_BARRIER_EVERY")) barrier_every = std::max(1, std::atoi(e));  // tuning
   auto hexf = [&](float v) {
     snprintf(buf, sizeof(buf), "%af", (double)v);
     return std::string(buf);
   };
-  // One stump as an expression. When every weight is a small integer and sum |w_j| * 255 * area_j < 2^24, every
-  // intermediate of the float expression w0*(float)r0 + w1*(float)r1 [+ w2*(float)r2] is an exactly representable
-  // integer, so the value equals (float) of the same combination computed in int32: corners shared by the rectangles
-  // merge, one conversion instead of three, no float multiplies. Otherwise the float expression is emitted term by term.
-  auto stump = [&](const HaarStumpDev& d, int stump_index) {
+  // One stump. When every weight is a small integer and sum |w_j| * 255 * area_j < 2^24, every intermediate of the
+  // float expression w0*(float)r0 + w1*(float)r1 [+ w2*(float)r2] is an exactly representable integer, so the value
+  // equals (float) of the same combination computed in int32: corners shared by the rectangles merge, one conversion
+  // instead of three, no float multiplies. Otherwise the float expression is emitted term by term.
+  // `win` names the window (variables x<stump>_<k><win>, base pointer b<win>, vnf<win>, acc<win>).
+  auto stump = [&](const HaarStumpDev& d, int stump_index, int local, const std::string& win) {
     const int fi = m.stump_feature[(size_t)stump_index];
     bool int_ok = true;
     double bound = 0;
@@ -806,6 +856,19 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
       bound += std::fabs((double)w) * 255.0 * (double)r[2] * (double)r[3] * (m.haar_tilted[(size_t)fi] ? 2.0 : 1.0);
     }
     if (bound >= 16777216.0) int_ok = false;
+    SpecStump out;
+    std::map<int, std::string> var;  // LDS offset -> variable holding that word
+    auto var_of = [&](int ofs) {
+      auto it = var.find(ofs);
+      if (it != var.end()) return it->second;
+      snprintf(buf, sizeof(buf), "x%d_%d%s", local, (int)var.size(), win.c_str());
+      const std::string name = buf;
+      var[ofs] = name;
+      out.decls += (out.decls.empty() ? "unsigned " : ", ") + name;
+      snprintf(buf, sizeof(buf), "%s = (unsigned)b%s[%d]; ", name.c_str(), win.c_str(), ofs);
+      out.loads += buf;
+      return name;
+    };
     std::string e = "{ float v = ";
     if (int_ok) {
       std::map<int, int> coef;  // LDS offset -> integer coefficient
@@ -815,55 +878,62 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
       std::map<int, std::vector<int>> by_coef;  // |coefficient| -> signed offsets (+ofs+1 / -(ofs+1))
       for (auto& kv : coef)
         if (kv.second) by_coef[std::abs(kv.second)].push_back(kv.second > 0 ? kv.first + 1 : -(kv.first + 1));
-      std::string t;
+      std::string tt;
       for (auto& g : by_coef) {
         std::string grp;
         for (int so : g.second) {
-          snprintf(buf, sizeof(buf), "%s(unsigned)b[%d]", so > 0 ? (grp.empty() ? "" : " + ") : " - ", std::abs(so) - 1);
-          grp += buf;
+          grp += so > 0 ? (grp.empty() ? "" : " + ") : " - ";
+          grp += var_of(std::abs(so) - 1);
         }
         if (grp.rfind(" - ", 0) == 0) grp = "0u" + grp;
-        snprintf(buf, sizeof(buf), "%s%du * (%s)", t.empty() ? "" : " + ", g.first, grp.c_str());  // unsigned: wrap-around is defined
-        t += buf;
+        snprintf(buf, sizeof(buf), "%s%du * (", tt.empty() ? "" : " + ", g.first);  // unsigned: wrap-around is defined
+        tt += buf + grp + ")";
       }
-      if (t.empty()) t = "0u";
-      e += "(float)(int)(" + t + ")";
+      if (tt.empty()) tt = "0u";
+      e += "(float)(int)(" + tt + ")";
     } else {
       for (int j = 0; j < d.nrect; j++) {
-        snprintf(buf, sizeof(buf), "%s%s * (float)(b[%d] - b[%d] - b[%d] + b[%d])", j ? " + " : "", hexf(d.w[j]).c_str(), d.ofs[j][0], d.ofs[j][1],
-                 d.ofs[j][2], d.ofs[j][3]);
-        e += buf;
+        const std::string a = var_of(d.ofs[j][0]), b2 = var_of(d.ofs[j][1]), c = var_of(d.ofs[j][2]), dd = var_of(d.ofs[j][3]);
+        e += std::string(j ? " + " : "") + hexf(d.w[j]) + " * (float)(int)(" + a + " - " + b2 + " - " + c + " + " + dd + ")";
       }
     }
-    return e + "; v *= vnf; acc += (double)(v < " + hexf(d.thr) + " ? " + hexf(d.left) + " : " + hexf(d.right) + "); }";
+    if (out.decls.empty()) out.decls = "";
+    else out.decls += ";";
+    out.compute = e + "; v *= vnf" + win + "; acc" + win + " += (double)(v < " + hexf(d.thr) + " ? " + hexf(d.left) + " : " + hexf(d.right) + "); }";
+    return out;
   };
-  for (int part = 0; part < 2; part++)
-    for (int step = 1; step <= 2; step++) {
-      if (part)
-        snprintf(buf, sizeof(buf), "template <>\n__device__ __forceinline__ double spec_stage_part<%d>(int st, int slice, int nsm1, const int32_t* b, float vnf) {\n", step);
-      else
-        snprintf(buf, sizeof(buf), "template <>\n__device__ __forceinline__ double spec_stage<%d>(int st, const int32_t* b, float vnf) {\n", step);
+  for (int step = 1; step <= 2; step++) {
+    snprintf(buf, sizeof(buf),
+             "template <>\n__device__ __forceinline__ double spec_stage<%d>(int st, int p_lo, int p_hi, const int32_t* b, float vnf) {\n", step);
+    o += buf;
+    o += "  double acc = 0.;\n  switch (st) {\n";
+    for (int s = 0; s < n_stages; s++) {
+      snprintf(buf, sizeof(buf), "    case %d: {\n", s);
       o += buf;
-      o += "  double acc = 0.;\n  switch (st) {\n";
-      for (int s = 0; s < n_stages; s++) {
-        snprintf(buf, sizeof(buf), "    case %d: {\n", s);
-        o += buf;
-        for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++) {
-          const HaarStumpDev& d = t[step - 1][(size_t)m.stage_first[(size_t)s] + i];
-          if (part) {  // stump i belongs to slice i mod ns (ns a power of two): a wave-uniform scalar test
-            snprintf(buf, sizeof(buf), "      if ((%d & nsm1) == slice) ", i);
-            o += buf;
-            o += stump(d, m.stage_first[(size_t)s] + i) + "\n";
-          } else {
-            o += "      " + stump(d, m.stage_first[(size_t)s] + i) + "\n";
-            // keep the scheduler from hoisting every LDS read of the stage to the top (register pressure -> spills)
-            if ((i + 1) % barrier_every == 0) o += "      __builtin_amdgcn_sched_barrier(0);\n";
-          }
-        }
-        o += "    } break;\n";
-      }
-      o += "    default: break;\n  }\n  return acc;\n}\n";
+      std::vector<SpecStump> st;
+      for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++)
+        st.push_back(stump(t[step - 1][(size_t)m.stage_first[(size_t)s] + i], m.stage_first[(size_t)s] + i, i, ""));
+      spec_emit_stage(o, st, depth, true);
+      o += "    } break;\n";
     }
+    o += "    default: break;\n  }\n  return acc;\n}\n";
+    // stage 0 for the two windows a thread owns in the dense phase: both windows' reads of a stump travel together
+    snprintf(buf, sizeof(buf),
+             "template <>\n__device__ __forceinline__ void spec_stage0_x2<%d>(const int32_t* ba, const int32_t* bb, float vnfa, float vnfb, double& "
+             "acc_a, double& acc_b) {\n  double acca = 0., accb = 0.;\n  {\n",
+             step);
+    o += buf;
+    {
+      std::vector<SpecStump> st;
+      for (int i = 0; i < m.stage_ntrees[0]; i++) {
+        const HaarStumpDev& d = t[step - 1][(size_t)m.stage_first[0] + i];
+        SpecStump a = stump(d, m.stage_first[0] + i, i, "a"), b2 = stump(d, m.stage_first[0] + i, i, "b");
+        st.push_back(SpecStump{a.loads + b2.loads, a.decls + " " + b2.decls, a.compute + " " + b2.compute});
+      }
+      spec_emit_stage(o, st, depth, false);
+    }
+    o += "  }\n  acc_a = acca;\n  acc_b = accb;\n}\n";
+  }
   return o;
 }
 
@@ -874,8 +944,9 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages) {
   build_lbp_stumps<1>(m, t[0]);
   build_lbp_stumps<2>(m, t[1]);
   n_stages = std::min<int>(n_stages, (int)m.stage_ntrees.size());
+  const int depth = std::min(spec_prefetch_depth(), 2);  // 16 words per stump in flight
   std::string o;
-  char buf[768];
+  char buf[1024];
   int n_stumps = 0;
   for (int s = 0; s < n_stages; s++) n_stumps += m.stage_ntrees[(size_t)s];
   o += "static __device__ const int kSpecSubsets[][8] = {\n";
@@ -891,47 +962,60 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages) {
     snprintf(b2, sizeof(b2), "%af", (double)v);
     return std::string(b2);
   };
-  auto stump = [&](const LbpStumpDev& d, int index) {
-    const int* p = d.ofs;
-    snprintf(buf, sizeof(buf),
-             "{ const int c = b[%d] - b[%d] - b[%d] + b[%d]; const int lbp = (b[%d] - b[%d] - b[%d] + b[%d] >= c ? 128 : 0) | "
-             "(b[%d] - b[%d] - b[%d] + b[%d] >= c ? 64 : 0) | (b[%d] - b[%d] - b[%d] + b[%d] >= c ? 32 : 0) | "
-             "(b[%d] - b[%d] - b[%d] + b[%d] >= c ? 16 : 0) | (b[%d] - b[%d] - b[%d] + b[%d] >= c ? 8 : 0) | "
-             "(b[%d] - b[%d] - b[%d] + b[%d] >= c ? 4 : 0) | (b[%d] - b[%d] - b[%d] + b[%d] >= c ? 2 : 0) | "
-             "(b[%d] - b[%d] - b[%d] + b[%d] >= c ? 1 : 0); ",
-             p[5], p[6], p[9], p[10], p[0], p[1], p[4], p[5], p[1], p[2], p[5], p[6], p[2], p[3], p[6], p[7], p[6], p[7], p[10], p[11], p[10],
-             p[11], p[14], p[15], p[9], p[10], p[13], p[14], p[8], p[9], p[12], p[13], p[4], p[5], p[8], p[9]);
-    std::string e = buf;
-    snprintf(buf, sizeof(buf), "acc += (double)((kSpecSubsets[%d][lbp >> 5] & (1 << (lbp & 31))) ? %s : %s); }", index, hexf(d.left).c_str(),
-             hexf(d.right).c_str());
-    return e + buf;
-  };
-  for (int part = 0; part < 2; part++)
-    for (int step = 1; step <= 2; step++) {
-      if (part)
-        snprintf(buf, sizeof(buf), "template <>\n__device__ __forceinline__ double spec_stage_part<%d>(int st, int slice, int nsm1, const int32_t* b, float vnf) {\n", step);
-      else
-        snprintf(buf, sizeof(buf), "template <>\n__device__ __forceinline__ double spec_stage<%d>(int st, const int32_t* b, float vnf) {\n", step);
-      o += buf;
-      o += "  double acc = 0.;\n  switch (st) {\n";
-      for (int s = 0; s < n_stages; s++) {
-        snprintf(buf, sizeof(buf), "    case %d: {\n", s);
-        o += buf;
-        for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++) {
-          const int idx = m.stage_first[(size_t)s] + i;
-          const LbpStumpDev& d = t[step - 1][(size_t)idx];
-          if (part) {
-            snprintf(buf, sizeof(buf), "      if ((%d & nsm1) == slice) ", i);
-            o += buf;
-            o += stump(d, idx) + "\n";
-          } else {
-            o += "      " + stump(d, idx) + "\n      __builtin_amdgcn_sched_barrier(0);\n";
-          }
-        }
-        o += "    } break;\n";
-      }
-      o += "    default: break;\n  }\n  return acc;\n}\n";
+  auto stump = [&](const LbpStumpDev& d, int index, int local, const std::string& win) {
+    SpecStump out;
+    std::string P[16];
+    for (int k = 0; k < 16; k++) {
+      snprintf(buf, sizeof(buf), "p%d_%d%s", local, k, win.c_str());
+      P[k] = buf;
+      out.decls += (k ? ", " : "int ") + P[k];
+      snprintf(buf, sizeof(buf), "%s = b%s[%d]; ", P[k].c_str(), win.c_str(), d.ofs[k]);
+      out.loads += buf;
     }
+    out.decls += ";";
+    auto cell = [&](int a, int b2, int c, int dd) { return P[a] + " - " + P[b2] + " - " + P[c] + " + " + P[dd]; };
+    std::string e = "{ const int c = " + cell(5, 6, 9, 10) + "; const int lbp = (" + cell(0, 1, 4, 5) + " >= c ? 128 : 0) | (" + cell(1, 2, 5, 6) +
+                    " >= c ? 64 : 0) | (" + cell(2, 3, 6, 7) + " >= c ? 32 : 0) | (" + cell(6, 7, 10, 11) + " >= c ? 16 : 0) | (" +
+                    cell(10, 11, 14, 15) + " >= c ? 8 : 0) | (" + cell(9, 10, 13, 14) + " >= c ? 4 : 0) | (" + cell(8, 9, 12, 13) +
+                    " >= c ? 2 : 0) | (" + cell(4, 5, 8, 9) + " >= c ? 1 : 0); ";
+    snprintf(buf, sizeof(buf), "acc%s += (double)((kSpecSubsets[%d][lbp >> 5] & (1 << (lbp & 31))) ? %s : %s); }", win.c_str(), index,
+             hexf(d.left).c_str(), hexf(d.right).c_str());
+    out.compute = e + buf;
+    return out;
+  };
+  for (int step = 1; step <= 2; step++) {
+    snprintf(buf, sizeof(buf),
+             "template <>\n__device__ __forceinline__ double spec_stage<%d>(int st, int p_lo, int p_hi, const int32_t* b, float vnf) {\n", step);
+    o += buf;
+    o += "  double acc = 0.;\n  switch (st) {\n";
+    for (int s = 0; s < n_stages; s++) {
+      snprintf(buf, sizeof(buf), "    case %d: {\n", s);
+      o += buf;
+      std::vector<SpecStump> st;
+      for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++) {
+        const int idx = m.stage_first[(size_t)s] + i;
+        st.push_back(stump(t[step - 1][(size_t)idx], idx, i, ""));
+      }
+      spec_emit_stage(o, st, depth, true);
+      o += "    } break;\n";
+    }
+    o += "    default: break;\n  }\n  return acc;\n}\n";
+    snprintf(buf, sizeof(buf),
+             "template <>\n__device__ __forceinline__ void spec_stage0_x2<%d>(const int32_t* ba, const int32_t* bb, float vnfa, float vnfb, double& "
+             "acc_a, double& acc_b) {\n  double acca = 0., accb = 0.;\n  {\n",
+             step);
+    o += buf;
+    {
+      std::vector<SpecStump> st;
+      for (int i = 0; i < m.stage_ntrees[0]; i++) {
+        const int idx = m.stage_first[0] + i;
+        SpecStump a = stump(t[step - 1][(size_t)idx], idx, i, "a"), b2 = stump(t[step - 1][(size_t)idx], idx, i, "b");
+        st.push_back(SpecStump{a.loads + b2.loads, a.decls + " " + b2.decls, a.compute + " " + b2.compute});
+      }
+      spec_emit_stage(o, st, std::min(depth, 1), false);
+    }
+    o += "  }\n  acc_a = acca;\n  acc_b = accb;\n}\n";
+  }
   return o;
 }
 
@@ -1534,21 +1618,32 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     int f0, nf, slot;
     const uint8_t* dptr;
     size_t rs, fs;
+    int cap;       // capacity of the candidate lists this pass was launched with
+    unsigned gen;  // generation of the candidate lists it wrote into
   };
   std::vector<CandOut> got;
-  // fetches the results of a launched pass; on candidate-list overflow grows the lists and redoes the pass synchronously
-  auto retire = [&](const Pass& ps) -> cc_status {
+  unsigned list_gen = 0;  // bumped whenever the candidate lists are released and regrown
+  // Fetches the results of a launched pass. On candidate-list overflow the lists grow and the pass is redone
+  // synchronously. Growing frees the lists of BOTH slots, so the pass already in flight in the other slot loses its
+  // results: it notices (its generation is stale) when its own turn comes and is redone as well. A pass is judged
+  // against the capacity it was launched with, not the current one.
+  auto retire = [&](Pass ps) -> cc_status {
     for (;;) {
       CC_HIP(hipEventSynchronize(d->pass_done[ps.slot]));
       const int raw = d->h_counts[2 * ps.slot], kept = d->h_counts[2 * ps.slot + 1];
-      if (raw > d->cand_cap) {
+      if (raw > ps.cap || ps.gen != list_gen) {
         CC_HIP(hipStreamSynchronize(d->stream));
-        d->cand_cap = raw + raw / 2;
-        d->d_cands.release();
-        d->d_out[0].release();
-        d->d_out[1].release();
+        if (raw > d->cand_cap) {
+          d->cand_cap = raw + raw / 2;
+          d->d_cands.release();
+          d->d_out[0].release();
+          d->d_out[1].release();
+          list_gen++;
+        }
         cc_status st2 = run_device_pass(d, P, ps.dptr, ps.nf, ps.rs, ps.fs, debug, ps.slot);
         if (st2 != CC_OK) return st2;
+        ps.cap = d->cand_cap;
+        ps.gen = list_gen;
         CC_HIP(hipMemcpyAsync(d->h_counts + 2 * ps.slot, d->d_counts[ps.slot].p, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
         CC_HIP(hipEventRecord(d->pass_done[ps.slot], d->stream));
         continue;
@@ -1588,6 +1683,8 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     }
     stt = run_device_pass(d, P, ps.dptr, ps.nf, ps.rs, ps.fs, debug, slot);
     if (stt != CC_OK) return stt;
+    ps.cap = d->cand_cap;
+    ps.gen = list_gen;
     if (want_results) {
       CC_HIP(hipMemcpyAsync(d->h_counts + 2 * slot, d->d_counts[slot].p, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
       CC_HIP(hipEventRecord(d->pass_done[slot], d->stream));
@@ -1663,13 +1760,16 @@ static const char kSpecPrelude[] =
     "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
 
 // Compiles `src` for `arch`; identical (source, options) pairs are served from a per-process cache.
-static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, bool lbp, std::vector<char>& code) {
+static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, bool lbp, int win_w, int win_h, std::vector<char>& code) {
   static std::mutex mu;
   static std::map<std::string, std::vector<char>> cache;
   const std::string o_arch = "--offload-arch=" + arch, o_k = "-DCC_SPEC_STAGES=" + std::to_string(n_stages);
   const std::string o_ty = "-DCC_TILE_Y=" + std::to_string(TILE_Y), o_th = "-DCC_EVAL_THREADS=" + std::to_string(EVAL_THREADS);
   // same code generation rules as the ahead-of-time build (Makefile): no FMA contraction, no fast-math
-  const char* opts[] = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str(), "-DCC_SPEC_LBP"};
+  std::string o_w = "-DCC_EVAL_MIN_WAVES_PER_EU=" + std::to_string(CC_EVAL_MIN_WAVES_PER_EU);
+  if (const char* e = std::getenv("CCAMD_SPEC_WAVES_PER_EU")) o_w = "-DCC_EVAL_MIN_WAVES_PER_EU=" + std::to_string(std::max(1, std::min(8, std::atoi(e))));  // tuning
+  const std::string o_w0 = "-DCC_SPEC_W0=" + std::to_string(win_w), o_h0 = "-DCC_SPEC_H0=" + std::to_string(win_h);  // tile geometry folds to constants
+  const char* opts[] = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str(), o_w.c_str(), o_w0.c_str(), o_h0.c_str(), "-DCC_SPEC_LBP"};
   const int n_opts = (int)(sizeof(opts) / sizeof(opts[0])) - (lbp ? 0 : 1);
   std::string key;  // everything the code object depends on: options, then the source
   for (int i = 0; i < n_opts; i++) key += std::string(opts[i]) + " ";
@@ -1784,7 +1884,7 @@ static cc_status spec_build(const Cascade& m, int n_stages, const std::string& a
   if (pos == std::string::npos) return set_error(CC_ERR_HIP, "cc_detector_specialize: kernel source has no specialisation marker");
   src.replace(pos, marker.size(), spec_stage_source(m, k));
   k_out = k;
-  return compile_specialised(src, arch, k, m.feature_type == CC_FEATURE_LBP, code);
+  return compile_specialised(src, arch, k, m.feature_type == CC_FEATURE_LBP, m.win_w, m.win_h, code);
 }
 
 // Device half: load the code object and make it the detector's cascade kernel. Owning thread only.
@@ -1910,6 +2010,7 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   d->early_skip = std::getenv("CCAMD_NO_EARLY_SKIP") ? 0 : 1;
   d->full_sqsum = std::getenv("CCAMD_FULL_SQSUM") ? 1 : 0;
   if (const char* e = std::getenv("CCAMD_PIPELINE_PASSES")) d->pipeline_passes = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("CCAMD_CAND_CAP")) d->cand_cap = std::max(16, std::atoi(e));  // initial candidate-list capacity (tests: forces the overflow path)
   d->even_passes = std::getenv("CCAMD_EVEN_PASSES") ? 1 : 0;
   if (const char* e = std::getenv("CCAMD_DEBUG_EXTRA_LDS")) {  // occupancy experiments: pad the per-block LDS request
     d->lds += (size_t)std::max(0, std::atoi(e));

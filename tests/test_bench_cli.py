@@ -1,0 +1,51 @@
+"""bench.py as the driver calls it: `python bench.py --gpus N` must start its own ranks (no launcher in front of it)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_multi_rank_launch_without_gpu_fails_loudly_and_does_not_hang():
+    """No GPU here: every rank must die with an error and the parent must return non-zero promptly (it terminates the
+    surviving ranks instead of waiting for a rendezvous that cannot complete)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = _run(["--gpus", "2", "--backend", "gloo", "--frames", "1", "--steps", "1", "--warmup", "0", "--width", "320", "--height", "240",
+              "--cpu-frames", "0"], timeout=300)
+    assert r.returncode != 0
+    assert not r.stdout.strip().startswith("{")  # no headline number without a device
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """The N > 1 leg end to end on the one-GPU box: two ranks share the card, detections are gathered over gloo
+    (the RCCL path needs one GPU per rank; the driver runs that)."""
+    r = _run(["--gpus", "2", "--backend", "gloo", "--frames", "2", "--steps", "1", "--warmup", "1", "--width", "640", "--height", "480",
+              "--cpu-frames", "0"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["frames_per_gpu_per_step"] == 2
+    assert out["value"] > 0 and "roofline" in out
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_line_has_roofline_and_cpu_baseline():
+    r = _run(["--frames", "2", "--steps", "1", "--warmup", "1", "--width", "640", "--height", "480", "--cpu-frames", "1"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1
+    assert out["roofline"]["bound"] in ("hbm", "mfma") and out["roofline"]["achieved"] > 0
+    assert out["cpu_baseline"]["rectangles_identical_to_gpu"] is True

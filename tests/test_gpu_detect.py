@@ -175,3 +175,30 @@ def test_profiling_counters(lbp_xml):
     p.detectMultiScale(frame_natural(640, 480, 1), 1.1, 3)
     t = p.timings(reset=True)
     assert t["frames"] == 1 and t["grid_windows"] == 585373 and t["eval_launches"] == 1 and t["eval_ms"] > 0
+
+
+def test_candidate_list_overflow_in_a_multi_pass_batch(monkeypatch):
+    """A weak cascade passes almost every window: the candidate lists overflow on the first pass of a batch while the next
+    pass is already in flight with the old capacity. Both must be redone; every frame's rectangles equal the oracle's."""
+    from tests import cascade_factory as cf
+    cat = orc.haar_catalog(24, 24, 0)
+    feats = cat[[1234]].copy()
+    xml_text = cf.haar_xml(feats, [(np.float32(-1.0), [([(0, -1, 0, np.float32(0.0))], [1.0, 1.0])])], mode="BASIC")
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False) as f:
+        f.write(xml_text)
+        path = f.name
+    frames = np.stack([frame_natural(200, 150, 90 + i) for i in range(7)])
+    o = orc.load_cascade_xml(path)
+    want = [orc.detect_multiscale(o, frames[i], 1.2, 0, nthreads=4) for i in range(7)]
+    assert min(len(w) for w in want) > 600  # far more candidates per frame than the initial capacity below
+    monkeypatch.setenv("CCAMD_CAND_CAP", "512")
+    for mb in (8, 2):
+        p = cc.CascadeClassifier(path, max_batch=mb)  # fresh detector: the first call meets the small lists
+        for _ in range(2):  # the second call runs with the grown lists
+            got = p.detect_batch(frames, 1.2, 0)
+            for i in range(7):
+                a = got[i][np.lexsort(got[i].T[::-1])]
+                b = want[i][np.lexsort(want[i].T[::-1])]
+                assert a.shape == b.shape and (a == b).all(), (mb, i)
+    os.unlink(path)

@@ -1,0 +1,203 @@
+// Micro-measurements that the cascade-kernel design leans on (run on the GPU box, prints one line per test):
+//   * issue cost of the VALU instructions of a stump evaluation (v_add_u32, v_cvt_f32_i32, v_mul_f32, v_cndmask, v_add_f64)
+//     at 1 / 2 / 4 / 8 wavefronts per SIMD, with the full EXEC mask and with only the lower 32 lanes enabled;
+//   * LDS cycles of the gather forms: ds_read_b32 on consecutive / strided / random words, ds_read2_b32, ds_read_b64.
+// Build: hipcc --offload-arch=gfx950 -O3 -o microbench_cu tools/microbench_cu.hip
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                     \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));   \
+      exit(1);                                                                    \
+    }                                                                             \
+  } while (0)
+
+constexpr int ITER = 2048;
+
+template <int OP, bool HALF>
+__global__ __launch_bounds__(1024) void k_valu(unsigned long long* out, int* sink) {
+  int a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;
+  float f0 = a0, f1 = a1, f2 = a2, f3 = a3, f4 = a4, f5 = a5, f6 = a6, f7 = a7;
+  const bool active = !HALF || (threadIdx.x & 63) < 32;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (active) {
+    for (int i = 0; i < ITER; i++) {
+      if (OP == 0) {
+        asm volatile(
+            "v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+            "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+            : "v"(i));
+      } else if (OP == 1) {
+        asm volatile(
+            "v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+            "v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n"
+            : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)
+            : "v"(d0 * 0.0 + 1.0));
+      } else if (OP == 2) {
+        asm volatile(
+            "v_cvt_f32_i32 %0, %8\n v_cvt_f32_i32 %1, %9\n v_cvt_f32_i32 %2, %10\n v_cvt_f32_i32 %3, %11\n"
+            "v_cvt_f32_i32 %4, %12\n v_cvt_f32_i32 %5, %13\n v_cvt_f32_i32 %6, %14\n v_cvt_f32_i32 %7, %15\n"
+            : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3), "=v"(f4), "=v"(f5), "=v"(f6), "=v"(f7)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+      } else if (OP == 3) {
+        asm volatile(
+            "v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+            "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+            : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7)
+            : "v"(1.0001f));
+      } else if (OP == 4) {  // compare + select of a double (two v_cndmask) + f64 add: the vote of a stump
+        asm volatile(
+            "v_cmp_lt_f32 vcc, %2, %3\n v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %6, %7, vcc\n"
+            "v_cmp_lt_f32 vcc, %3, %2\n v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %6, %7, vcc\n"
+            "v_cmp_lt_f32 vcc, %2, %3\n v_cndmask_b32 %0, %4, %5, vcc\n"
+            : "+v"(a0), "+v"(a1)
+            : "v"(f0), "v"(f1), "v"(a2), "v"(a3), "v"(a4), "v"(a5)
+            : "vcc");
+      }
+    }
+  }
+  __syncthreads();  // every wavefront of the block is done (the oldest one wins arbitration and would finish early)
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 123456789 || d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 == 1.5 ||
+      f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 == 1.25f)
+    sink[0] = 1;
+}
+
+// LDS gathers: every lane reads 8 words per iteration at (addr_k + iteration-independent offset); `mode` picks the form.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_lds(const int* __restrict__ addr, unsigned long long* out, int* sink) {
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = i;
+  const int lane = threadIdx.x & 63;
+  int a[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = addr[k * 64 + lane] * 4;  // byte addresses
+  __syncthreads();
+  int s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+  int t0v, t1v, t2v, t3v, t4v, t5v, t6v, t7v;
+  long long w0, w1, w2, w3, w4, w5, w6, w7;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < ITER; i++) {
+    if (MODE == 0) {  // 8 x ds_read_b32
+      asm volatile(
+          "ds_read_b32 %0, %8\n ds_read_b32 %1, %9\n ds_read_b32 %2, %10\n ds_read_b32 %3, %11\n"
+          "ds_read_b32 %4, %12\n ds_read_b32 %5, %13\n ds_read_b32 %6, %14\n ds_read_b32 %7, %15\n s_waitcnt lgkmcnt(0)\n"
+          : "=&v"(t0v), "=&v"(t1v), "=&v"(t2v), "=&v"(t3v), "=&v"(t4v), "=&v"(t5v), "=&v"(t6v), "=&v"(t7v)
+          : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+      s0 += t0v; s1 += t1v; s2 += t2v; s3 += t3v; s4 += t4v; s5 += t5v; s6 += t6v; s7 += t7v;
+    } else if (MODE == 1) {  // 4 x ds_read2_b32 (words a and a + 40)
+      asm volatile(
+          "ds_read2_b32 %0, %4 offset1:40\n ds_read2_b32 %1, %5 offset1:40\n ds_read2_b32 %2, %6 offset1:40\n ds_read2_b32 %3, %7 offset1:40\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+          : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+      s0 += (int)w0; s1 += (int)(w0 >> 32); s2 += (int)w1; s3 += (int)(w1 >> 32); s4 += (int)w2; s5 += (int)(w2 >> 32); s6 += (int)w3; s7 += (int)(w3 >> 32);
+    } else {  // 8 x ds_read_b64 (addresses rounded down to 8 bytes by the host)
+      asm volatile(
+          "ds_read_b64 %0, %8\n ds_read_b64 %1, %9\n ds_read_b64 %2, %10\n ds_read_b64 %3, %11\n"
+          "ds_read_b64 %4, %12\n ds_read_b64 %5, %13\n ds_read_b64 %6, %14\n ds_read_b64 %7, %15\n s_waitcnt lgkmcnt(0)\n"
+          : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(w4), "=&v"(w5), "=&v"(w6), "=&v"(w7)
+          : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+      s0 += (int)w0 + (int)(w0 >> 32); s1 += (int)w1; s2 += (int)w2; s3 += (int)w3; s4 += (int)w4; s5 += (int)w5; s6 += (int)w6; s7 += (int)w7;
+    }
+  }
+  __syncthreads();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  if (s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7 == 123456789) sink[0] = 1;
+}
+
+static double median_cycles(unsigned long long* d_out, int n) {
+  std::vector<unsigned long long> h((size_t)n);
+  CK(hipMemcpy(h.data(), d_out, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
+  std::sort(h.begin(), h.end());
+  return (double)h[(size_t)n / 2];
+}
+
+int main() {
+  unsigned long long* d_out;
+  int *d_sink, *d_addr;
+  const int blocks = 256;
+  CK(hipMalloc(&d_out, sizeof(unsigned long long) * blocks));
+  CK(hipMalloc(&d_sink, 4));
+  CK(hipMalloc(&d_addr, 4 * 512));
+  const char* opname[] = {"v_add_u32", "v_add_f64", "v_cvt_f32_i32", "v_mul_f32", "cmp+2cndmask(x8 of 9 instr)"};
+  for (int op = 0; op < 5; op++)
+    for (int half = 0; half < 2; half++)
+      for (int wps : {1, 2, 4}) {
+        const int threads = 256 * wps;
+        auto launch = [&](auto kern) {
+          hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d_out, d_sink);
+          hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d_out, d_sink);
+          CK(hipDeviceSynchronize());
+        };
+        switch (op * 2 + half) {
+          case 0: launch(k_valu<0, false>); break;
+          case 1: launch(k_valu<0, true>); break;
+          case 2: launch(k_valu<1, false>); break;
+          case 3: launch(k_valu<1, true>); break;
+          case 4: launch(k_valu<2, false>); break;
+          case 5: launch(k_valu<2, true>); break;
+          case 6: launch(k_valu<3, false>); break;
+          case 7: launch(k_valu<3, true>); break;
+          case 8: launch(k_valu<4, false>); break;
+          case 9: launch(k_valu<4, true>); break;
+        }
+        const double cyc = median_cycles(d_out, blocks);
+        const double instr_per_simd = (double)ITER * 8 * wps;  // one block per CU: wps wavefronts on each SIMD
+        printf("VALU %-28s exec=%s waves/SIMD=%d : %.2f cycles per wave-instruction per SIMD\n", opname[op], half ? "lower32" : "full", wps,
+               cyc / instr_per_simd);
+      }
+  // LDS address patterns (word index per lane, 8 slots)
+  struct Pat {
+    const char* name;
+    std::vector<int> w;
+  };
+  std::vector<Pat> pats;
+  auto mk = [&](const char* name, auto f) {
+    Pat p{name, std::vector<int>(512)};
+    for (int k = 0; k < 8; k++)
+      for (int l = 0; l < 64; l++) p.w[(size_t)k * 64 + l] = f(k, l) & 8191;
+    pats.push_back(p);
+  };
+  srand(7);
+  mk("consecutive (lane)", [](int k, int l) { return k * 200 + l; });
+  mk("stride 2 (2*lane)", [](int k, int l) { return k * 200 + 2 * l; });
+  mk("random in 6080 words", [](int, int) { return rand() % 6080; });
+  mk("all lanes one bank (32*lane)", [](int k, int l) { return k + 32 * l; });
+  mk("pairs: 2*lane (b64 natural)", [](int k, int l) { return k * 200 + 2 * l; });
+  mk("scattered, banks distinct per half", [](int k, int l) { return ((l * 7 + k * 3) % 32) + 32 * ((l * 13 + k) % 150); });
+  for (int mode = 0; mode < 3; mode++)
+    for (auto& p : pats)
+      for (int wps : {1, 4}) {
+        std::vector<int> w = p.w;
+        if (mode == 2)
+          for (auto& x : w) x &= ~1;
+        CK(hipMemcpy(d_addr, w.data(), 4 * 512, hipMemcpyHostToDevice));
+        const int threads = 256 * wps;
+        for (int rep = 0; rep < 2; rep++) {
+          if (mode == 0) hipLaunchKernelGGL(k_lds<0>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
+          if (mode == 1) hipLaunchKernelGGL(k_lds<1>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
+          if (mode == 2) hipLaunchKernelGGL(k_lds<2>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
+        }
+        CK(hipDeviceSynchronize());
+        const double cyc = median_cycles(d_out, blocks);
+        const double n_instr = (double)ITER * (mode == 1 ? 4 : 8) * wps * 4;  // wave-instructions per CU
+        const char* mname[] = {"ds_read_b32", "ds_read2_b32", "ds_read_b64"};
+        printf("LDS %-13s %-32s waves/CU=%2d : %.2f cycles per wave-instruction per CU (%.1f B/clk/CU)\n", mname[mode], p.name, wps * 4,
+               cyc / n_instr, (mode == 0 ? 256.0 : 512.0) / (cyc / n_instr));
+      }
+  return 0;
+}
