@@ -648,6 +648,7 @@ struct cc_detector {
   hipStream_t copy_stream = nullptr;
   hipEvent_t pass_done[2] = {nullptr, nullptr};
   int cand_cap = 0;
+  DevBuf<unsigned long long> d_stamps;  // CCAMD_DEBUG_STAMPS experiments
   DevBuf<int32_t> d_dbg_codes;
   DevBuf<double> d_dbg_sums;
   DevBuf<uint8_t> d_dbg_visited;
@@ -777,7 +778,7 @@ static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) 
 // The code is software-pipelined by construction: the LDS reads of stump i + D are issued before stump i is computed,
 // and scheduling barriers pin that order (left alone, the compiler emits read, wait, compute per stump and every
 // wavefront spends most of its time waiting for the LDS round trip). One copy of a stage serves the whole-stage call and
-// the stump-split calls: the stage is cut into EVAL_WAVES contiguous parts, a call evaluates parts [p_lo, p_hi) and only
+// the stump-split calls: the stage is cut into SPEC_PARTS contiguous parts, a call evaluates parts [p_lo, p_hi) and only
 // its first part runs the prologue that issues the first D stumps' reads (a part's tail prefetches into the next part,
 // so consecutive parts run without a pipeline drain).
 struct SpecStump {
@@ -797,7 +798,7 @@ static void spec_emit_stage(std::string& o, const std::vector<SpecStump>& st, in
   const int nt = (int)st.size();
   static const char* kSB = "      __builtin_amdgcn_sched_barrier(0);\n";
   for (const SpecStump& t : st) o += "      " + t.decls + "\n";
-  const int P = parts ? EVAL_WAVES : 1;
+  const int P = parts ? SPEC_PARTS : 1;
   char buf[128];
   for (int k = 0; k < P; k++) {
     const int e0 = (int)((long long)k * nt / P), e1 = (int)((long long)(k + 1) * nt / P);
@@ -1404,6 +1405,12 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.cands = d->d_cands.p;
     A.cand_count = d->d_counts[slot].p;
     A.cand_cap = d->cand_cap;
+    A.stamps = nullptr;
+    if (std::getenv("CCAMD_DEBUG_STAMPS")) {  // timing experiments: per-block phase stamps of the cascade kernel
+      CC_HIP(d->d_stamps.ensure((size_t)P->n_tiles * (size_t)nf * STAMP_SLOTS));
+      CC_HIP(hipMemsetAsync(d->d_stamps.p, 0, (size_t)P->n_tiles * (size_t)nf * STAMP_SLOTS * sizeof(unsigned long long), st));
+      A.stamps = d->d_stamps.p;
+    }
     A.dbg_codes = debug ? d->d_dbg_codes.p : nullptr;
     A.dbg_sums = debug ? d->d_dbg_sums.p : nullptr;
     A.tiles = P->d_tiles.p;
@@ -1440,6 +1447,17 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
                          d->d_masks.p, d->d_dbg_visited.p);
   }
   CC_HIP(hipGetLastError());
+  if (const char* path = std::getenv("CCAMD_DEBUG_STAMPS")) {  // dump [n_tiles * nf][STAMP_SLOTS] u64 (overwritten per pass)
+    CC_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h((size_t)P->n_tiles * (size_t)nf * STAMP_SLOTS);
+    CC_HIP(hipMemcpy(h.data(), d->d_stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(path, "wb")) {
+      const int hdr[4] = {P->n_tiles, nf, STAMP_SLOTS, 0};
+      std::fwrite(hdr, sizeof(int), 4, f);
+      std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+      std::fclose(f);
+    }
+  }
   d->tm.frames += nf;
   d->tm.grid_windows += P->windows * nf;
   d->tm.integral_elems += P->integral_elems * nf;
