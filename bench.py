@@ -51,6 +51,40 @@ def usable_cores():
     return n
 
 
+def kernel_source_sha16():
+    """Identifies the cascade-kernel sources a counter profile belongs to (first 16 hex digits of their sha256)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("cc_eval_kernel.inc", "cc_detect.hip"):
+        with open(os.path.join(ROOT, "cascadeclassifier_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def corner_reads_frame0(clf, frame, scale_factor):
+    """Integral-image corner reads of the reference algorithm on one frame: for every window the scan visits, 4 for the
+    variance rectangle (Haar) plus, for every stump of every stage the window reaches, 4 per rectangle (LBP: 16)."""
+    m = clf.model()
+    codes, sums, vis = clf.debug_windows(frame, scale_factor)
+    ns = len(m.stage_first)
+    if m.info["feature_type"] == 0:
+        nrect = 2 + (m.weights[:, 2] != 0).astype(np.int64)
+        per_weak = 4 * nrect[m.stump_feature]
+        base = 4
+    else:
+        per_weak = np.full(len(m.stump_feature), 16, np.int64)
+        base = 0
+    per_stage = np.array([per_weak[m.stage_first[s]:m.stage_first[s] + m.stage_ntrees[s]].sum() for s in range(ns)], np.int64)
+    cum = np.concatenate([[0], np.cumsum(per_stage)])  # cum[k] = reads of stages 0 .. k-1
+    # result codes: 1 = passed every stage, 0 = rejected by stage 0, -k = rejected by stage k (k >= 1); a Haar window that
+    # fails the variance test is reported as -1 with stage sum exactly 0 and reaches no stage
+    stages_run = np.where(codes == 1, ns, np.where(codes == 0, 1, -codes + 1)).astype(np.int64)
+    if m.info["feature_type"] == 0:
+        stages_run[(codes == -1) & (sums == 0.0)] = 0
+    reads = base + cum[np.clip(stages_run, 0, ns)]
+    return int(reads[vis != 0].sum())
+
+
 def spawn_ranks(n):
     """Starts n copies of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, 127.0.0.1 rendezvous on a free port) and
     waits for them. Returns the first non-zero exit status, or 0. If one rank dies the others are terminated, so a
@@ -191,19 +225,41 @@ def main():
     eval_ms = tm["eval_ms"] / max(tm["eval_launches"], 1)
     frames_per_launch = tm["frames"] / max(tm["eval_launches"], 1)
     ach = eval_bytes_per_frame * frames_per_launch / (eval_ms * 1e-3) / 1e9 if eval_ms > 0 else 0.0
-    # HBM traffic of the cascade kernel comes from PMC counters, which need their own rocprofv3 passes
-    # (tools/profile_bench.sh); the committed measurement is scaled to this run's frames per launch.
+    # Counter-based figures (HBM traffic, LDS / VALU busy) need their own rocprofv3 passes (tools/profile_bench.sh,
+    # tools/pmc_eval.sh): this run can only REPLAY the committed measurement, and does so only when that profile was
+    # taken from the very kernel sources this run executes (sha of the kernel files recorded next to the numbers).
+    src_sha = kernel_source_sha16()
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_traffic_k_eval_haar.json")
-    if inf["feature_type"] == 0 and os.path.exists(tfile) and (W, H) == (1920, 1080) and abs(args.scale_factor - 1.1) < 1e-12:
-        traffic = round(json.load(open(tfile))["hbm_bytes_per_frame"] * frames_per_launch)
-    # secondary limiter: LDS bandwidth of the corner gathers, from the committed PMC pass of the same kernel
+    traffic_note = None
+    tfile = os.path.join(ROOT, "profiles", "r02_traffic_k_eval.json")
+    kernel_name = "k_eval_spec" if spec_stages else ("k_eval_haar" if inf["feature_type"] == 0 else "k_eval_lbp")
+    if os.path.exists(tfile) and (W, H) == (1920, 1080) and abs(args.scale_factor - 1.1) < 1e-12:
+        tj = json.load(open(tfile))
+        if tj.get("kernel_src_sha16") == src_sha and tj.get("kernel") == kernel_name:
+            traffic = round(tj["hbm_bytes_per_frame"] * frames_per_launch)
+            traffic_note = {"replayed_from": "profiles/r02_traffic_k_eval.json", "profile_kernel_src_sha16": src_sha,
+                            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes, FETCH x2 (gfx950), scaled to this run's frames per launch"}
+        else:
+            traffic_note = {"refused": "profiles/r02_traffic_k_eval.json was measured on other kernel sources or another kernel "
+                                       f"({tj.get('kernel')}, {tj.get('kernel_src_sha16')} vs {kernel_name}, {src_sha}): re-run tools/profile_bench.sh"}
     secondary = None
-    pfile = os.path.join(ROOT, "profiles", "r01_pmc_eval.json")
-    if inf["feature_type"] == 0 and spec_stages and os.path.exists(pfile) and (W, H) == (1920, 1080):
+    pfile = os.path.join(ROOT, "profiles", "r02_pmc_eval.json")
+    if os.path.exists(pfile) and (W, H) == (1920, 1080):
         pj = json.load(open(pfile))
-        secondary = {"limiter": "LDS", "lds_pipeline_busy": pj["lds_pipeline_busy"], "lds_bank_conflict_share": pj["lds_bank_conflict_share"],
-                     "valu_busy": pj["valu_busy"], "source": "profiles/r01_pmc_eval.json (tools/pmc_eval.sh)"}
+        if pj.get("kernel_src_sha16") == src_sha and pj.get("kernel") == kernel_name:
+            secondary = {"lds_pipeline_busy": pj["lds_pipeline_busy"], "lds_bank_conflict_share": pj["lds_bank_conflict_share"],
+                         "valu_busy": pj["valu_busy"], "replayed_from": "profiles/r02_pmc_eval.json (tools/pmc_eval.sh)",
+                         "profile_kernel_src_sha16": src_sha}
+    # Secondary limiter measured IN THIS RUN: the rectangle-corner gathers the reference algorithm performs on the windows
+    # its scan visits (frame 0: 4 corners of the variance rectangle + 4 per rectangle of every stump the window reaches;
+    # LBP: 16 per stump), priced against the LDS gather peak (ds_read_b32: 128 B/clk/CU x 256 CUs x 2.4 GHz).
+    lds = None
+    if rank == 0 and not args.device_only and not os.environ.get("CCAMD_BENCH_NO_VISITED") and eval_ms > 0:
+        reads0 = corner_reads_frame0(clf, frames_host[0], args.scale_factor)
+        lds_peak = 256 * 128 * 2.4  # GB/s
+        lds_ach = reads0 * 4 * frames_per_launch / (eval_ms * 1e-3) / 1e9
+        lds = {"corner_reads_frame0": reads0, "achieved": round(lds_ach, 1), "peak": round(lds_peak, 1), "unit": "GB/s",
+               "frac": round(lds_ach / lds_peak, 4), "measured": "in this run (frame 0's result codes x per-stage corner counts, same launch time as `achieved`)"}
     out = {
         "metric": "detection Mwindows/sec (1080p, haarcascade_frontalface) + achieved HBM GB/s",
         "value": round(value, 3),
@@ -232,18 +288,20 @@ def main():
         "frames_per_s": round(B * world * args.steps / dt, 2),
         "kernel_ms_per_step": {k: round(tm[k] / args.steps, 4) for k in ("resize_ms", "integral_ms", "eval_ms", "finalize_ms")},
         "roofline": {
-            "kernel": "k_eval_spec" if spec_stages else ("k_eval_haar" if inf["feature_type"] == 0 else "k_eval_lbp"),
+            "kernel": kernel_name,
             "bound": "hbm",
             "achieved": round(ach, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 5),
             "traffic": traffic,
-            "traffic_source": "profiles/r01_traffic_k_eval_haar.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH x2 gfx950 correction, "
-                              "calibrated with tools/calibrate_fetch.py)" if traffic else None,
+            "traffic_source": traffic_note,
             "algorithmic_bytes_per_launch": round(eval_bytes_per_frame * frames_per_launch),
             "frames_per_launch": frames_per_launch,
             "avg_launch_ms": round(eval_ms, 4),
+            "kernel_src_sha16": src_sha,
+            "limiter": "LDS corner gathers + VALU issue, not HBM (see lds and secondary)",
+            "lds": lds,
             "secondary": secondary,
         },
     }

@@ -103,6 +103,7 @@ SIGNATURES = {
     "cc_detector_specialized_stages": (_i, [_vp]),
     "cc_cascade_compile_specialized": (_i, [_vp, _i, C.c_char_p, C.POINTER(C.c_size_t)]),
     "cc_detector_set_profiling": (_i, [_vp, _i]),
+    "cc_detector_graph_active": (_i, [_vp]),
     "cc_detector_get_timings": (_i, [_vp, C.POINTER(DetectorTimings), _i]),
     "cc_integral_u8": (_i, [_i, _vp, _i, _i, _sz, _vp, _vp, _vp]),
     "cc_resize_linear_exact_u8": (_i, [_i, _vp, _i, _i, _sz, _vp, _i, _i, _sz]),

@@ -121,8 +121,46 @@ class Mat {
   std::shared_ptr<uchar> buf_;
 };
 
-// Write-only XML FileStorage with the `<<` streaming protocol the reference's writers use
-// (names, scalars, "{" "}" "[" "]" "[:" "{:"), producing the <opencv_storage> layout OpenCV reads back.
+// Read side: one element of a parsed <opencv_storage> document. Covers what the reference's parameter readers use
+// (features.cpp:53-60, haarfeatures.cpp:38-52, cascadeclassifier.cpp:388-401): empty(), operator[], isString(),
+// conversion to int / float / double / std::string, operator>>, and iteration over children.
+class FileNode {
+ public:
+  struct Elem {
+    std::string name, text;
+    std::vector<std::shared_ptr<Elem>> kids;
+  };
+  FileNode() {}
+  explicit FileNode(std::shared_ptr<Elem> e) : e_(std::move(e)) {}
+  bool empty() const { return !e_; }
+  bool isNone() const { return !e_; }
+  bool isMap() const { return e_ && !e_->kids.empty() && e_->kids[0]->name != "_"; }
+  bool isSeq() const { return e_ && !e_->kids.empty() && e_->kids[0]->name == "_"; }
+  bool isInt() const;
+  bool isReal() const;
+  bool isString() const { return e_ && e_->kids.empty() && !text().empty() && !isInt() && !isReal(); }
+  size_t size() const { return e_ ? e_->kids.size() : 0; }
+  std::string name() const { return e_ ? e_->name : std::string(); }
+  FileNode operator[](const std::string& key) const;
+  FileNode operator[](const char* key) const { return (*this)[std::string(key)]; }
+  FileNode operator[](int i) const { return e_ && i >= 0 && (size_t)i < e_->kids.size() ? FileNode(e_->kids[(size_t)i]) : FileNode(); }
+  operator int() const;
+  operator float() const { return (float)(double)*this; }
+  operator double() const;
+  operator std::string() const { return text(); }
+  std::string text() const;  // trimmed character data
+
+ private:
+  std::shared_ptr<Elem> e_;
+};
+inline void operator>>(const FileNode& n, std::string& v) { v = (std::string)n; }
+inline void operator>>(const FileNode& n, int& v) { v = (int)n; }
+inline void operator>>(const FileNode& n, float& v) { v = (float)n; }
+inline void operator>>(const FileNode& n, double& v) { v = (double)n; }
+
+// XML FileStorage: the `<<` streaming protocol the reference's writers use (names, scalars, "{" "}" "[" "]" "[:" "{:"),
+// producing the <opencv_storage> layout OpenCV reads back; opened with READ it parses such a document (file, or the text
+// itself with READ | MEMORY) into FileNodes.
 class FileStorage {
  public:
   enum { READ = 0, WRITE = 1, MEMORY = 4 };
@@ -133,6 +171,10 @@ class FileStorage {
   bool isOpened() const { return opened_; }
   void release();
   std::string releaseAndGetString();
+  FileNode root() const { return FileNode(root_); }                // the <opencv_storage> element
+  FileNode getFirstTopLevelNode() const { return root()[0]; }
+  FileNode operator[](const std::string& key) const { return root()[key]; }
+  FileNode operator[](const char* key) const { return root()[std::string(key)]; }
   FileStorage& put(const std::string& s);
   FileStorage& putNumber(const std::string& text);
 
@@ -144,6 +186,7 @@ class FileStorage {
   };
   void element_open(const std::string& tag);
   void indent();
+  std::shared_ptr<FileNode::Elem> root_;  // READ mode
   std::string filename_;
   std::ostringstream out_;
   std::vector<Level> stack_;

@@ -25,13 +25,129 @@ thread_local RowCache g_row;
 
 }  // namespace
 
-// ---------------------------------------------------------------- cv::FileStorage (write-only XML)
+// ---------------------------------------------------------------- cv::FileStorage / cv::FileNode (XML)
 #ifndef CCAMD_USE_OPENCV
 namespace cv {
 
+namespace {
+// Minimal XML reader for <opencv_storage> documents: elements, character data, the five predefined entities; comments,
+// the XML declaration and attributes are skipped. Returns null on malformed input.
+std::shared_ptr<FileNode::Elem> parse_storage(const std::string& t) {
+  size_t i = 0;
+  std::vector<std::shared_ptr<FileNode::Elem>> stack;
+  std::shared_ptr<FileNode::Elem> top_level;
+  auto decode = [](const std::string& raw) {
+    std::string o;
+    for (size_t k = 0; k < raw.size(); k++) {
+      if (raw[k] != '&') {
+        o += raw[k];
+        continue;
+      }
+      const size_t e = raw.find(';', k);
+      if (e == std::string::npos) return raw;
+      const std::string ent = raw.substr(k + 1, e - k - 1);
+      o += ent == "lt" ? '<' : ent == "gt" ? '>' : ent == "amp" ? '&' : ent == "quot" ? '"' : ent == "apos" ? '\'' : '?';
+      k = e;
+    }
+    return o;
+  };
+  while (i < t.size()) {
+    if (t[i] != '<') {
+      const size_t e = t.find('<', i);
+      const std::string chunk = t.substr(i, (e == std::string::npos ? t.size() : e) - i);
+      if (!stack.empty()) stack.back()->text += decode(chunk);
+      i = e == std::string::npos ? t.size() : e;
+      continue;
+    }
+    if (t.compare(i, 4, "<!--") == 0) {
+      const size_t e = t.find("-->", i);
+      if (e == std::string::npos) return nullptr;
+      i = e + 3;
+      continue;
+    }
+    if (t.compare(i, 2, "<?") == 0) {
+      const size_t e = t.find("?>", i);
+      if (e == std::string::npos) return nullptr;
+      i = e + 2;
+      continue;
+    }
+    const size_t e = t.find('>', i);
+    if (e == std::string::npos) return nullptr;
+    std::string tag = t.substr(i + 1, e - i - 1);
+    i = e + 1;
+    if (!tag.empty() && tag[0] == '/') {
+      if (stack.empty() || stack.back()->name != tag.substr(1)) return nullptr;
+      auto done = stack.back();
+      stack.pop_back();
+      if (stack.empty()) top_level = done;
+      continue;
+    }
+    const bool self_closing = !tag.empty() && tag.back() == '/';
+    if (self_closing) tag.pop_back();
+    const size_t sp = tag.find_first_of(" \t\r\n");
+    auto el = std::make_shared<FileNode::Elem>();
+    el->name = tag.substr(0, sp);
+    if (el->name.empty()) return nullptr;
+    if (!stack.empty()) stack.back()->kids.push_back(el);
+    if (!self_closing)
+      stack.push_back(el);
+    else if (stack.empty())
+      top_level = el;
+  }
+  return stack.empty() ? top_level : nullptr;
+}
+}  // namespace
+
+std::string FileNode::text() const {
+  if (!e_) return std::string();
+  const std::string& t = e_->text;
+  const size_t a = t.find_first_not_of(" \t\r\n"), b = t.find_last_not_of(" \t\r\n");
+  return a == std::string::npos ? std::string() : t.substr(a, b - a + 1);
+}
+bool FileNode::isInt() const {
+  if (!e_ || !e_->kids.empty()) return false;
+  const std::string t = text();
+  if (t.empty()) return false;
+  char* end = nullptr;
+  (void)std::strtol(t.c_str(), &end, 10);
+  return end && *end == 0;
+}
+bool FileNode::isReal() const {
+  if (!e_ || !e_->kids.empty() || isInt()) return false;
+  const std::string t = text();
+  if (t.empty()) return false;
+  char* end = nullptr;
+  (void)std::strtod(t.c_str(), &end);
+  return end && *end == 0;
+}
+FileNode FileNode::operator[](const std::string& key) const {
+  if (e_)
+    for (const auto& k : e_->kids)
+      if (k->name == key) return FileNode(k);
+  return FileNode();
+}
+FileNode::operator int() const {  // like OpenCV: a missing node reads as 0
+  return e_ ? (int)std::strtol(text().c_str(), nullptr, 10) : 0;
+}
+FileNode::operator double() const { return e_ ? std::strtod(text().c_str(), nullptr) : 0.0; }
+
 bool FileStorage::open(const std::string& filename, int flags) {
   release();
-  if (!(flags & WRITE)) return false;  // reading cascades goes through cc_cascade_load_xml
+  root_.reset();
+  if (!(flags & WRITE)) {  // READ: parse the whole document (a file, or with MEMORY the text itself)
+    std::string text = filename;
+    if (!(flags & MEMORY)) {
+      std::ifstream f(filename, std::ios::binary);
+      if (!f) return false;
+      std::ostringstream ss;
+      ss << f.rdbuf();
+      text = ss.str();
+    }
+    auto top = parse_storage(text);
+    if (!top || top->name != "opencv_storage") return false;
+    root_ = top;
+    return true;
+  }
   filename_ = filename;
   memory_ = (flags & MEMORY) != 0;
   opened_ = true;

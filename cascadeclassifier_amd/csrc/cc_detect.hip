@@ -604,6 +604,7 @@ struct cc_detector {
   DevBuf<int> d_stage_ntrees, d_stage_first;
   DevBuf<float> d_stage_thr;
   int wave_below = 0;
+  int last_call_graph = 0;  // the last single-image call was one hipGraph launch (cc_detector_graph_active)
   int stop_after = -1;
   int split_stumps = 0;
   DevBuf<HaarStumpDev> d_haar1, d_haar2;
@@ -1539,9 +1540,11 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       d->eval_pending[0] = d->eval_pending[1] = false;
     }
     bool launched = false;
+    d->last_call_graph = 0;
     if (P->graph_exec && P->graph_key == key_now()) {
       CC_HIP(hipGraphLaunch(P->graph_exec, d->stream));
       launched = true;
+      d->last_call_graph = 1;
     } else if (P->graph_warm) {
       if (P->graph_exec) (void)hipGraphExecDestroy(P->graph_exec);
       P->graph_exec = nullptr;
@@ -1555,7 +1558,8 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       cc_status s2 = CC_OK;
       {
         std::lock_guard<std::mutex> capture_lock(capture_mu);
-        ce = hipStreamBeginCapture(d->stream, hipStreamCaptureModeRelaxed);
+        ce = std::getenv("CCAMD_DEBUG_FAIL_CAPTURE") ? hipErrorStreamCaptureUnsupported  // tests: the fallback path
+                                                     : hipStreamBeginCapture(d->stream, hipStreamCaptureModeRelaxed);
         if (ce == hipSuccess) {
           s2 = body();
           ce = hipStreamEndCapture(d->stream, &graph);
@@ -1564,9 +1568,10 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       if (ce == hipSuccess && s2 == CC_OK && graph) ie = hipGraphInstantiate(&P->graph_exec, graph, nullptr, nullptr, 0);
       if (graph) (void)hipGraphDestroy(graph);
       if (ce != hipSuccess || s2 != CC_OK || ie != hipSuccess || !P->graph_exec) {
-        if (std::getenv("CCAMD_TIMING"))
-          std::fprintf(stderr, "[ccamd] graph capture failed (begin/end: %s, body status %d, instantiate: %s): using ordinary launches\n",
-                       hipGetErrorString(ce), (int)s2, hipGetErrorString(ie));
+        // said once per detector, on stderr: the call still succeeds, only the launch-bound single-image path gets slower
+        std::fprintf(stderr, "[ccamd] hipGraph capture of the single-image pass failed (begin/end: %s, body status %d, instantiate: %s): "
+                             "this detector uses ordinary launches from now on\n",
+                     hipGetErrorString(ce), (int)s2, hipGetErrorString(ie));
         (void)hipGetLastError();
         P->graph_exec = nullptr;
         d->use_graph = 0;  // ordinary launches from now on (this call included)
@@ -1574,6 +1579,7 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
         P->graph_key = key_now();
         CC_HIP(hipGraphLaunch(P->graph_exec, d->stream));
         launched = true;
+        d->last_call_graph = 1;
       }
     }
     if (!launched) {
@@ -2144,6 +2150,11 @@ cc_status cc_cascade_compile_specialized(const cc_cascade* c, int n_stages, cons
   if (st != CC_OK) return st;
   *code_bytes = code.size();
   return CC_OK;
+}
+
+int cc_detector_graph_active(const cc_detector* d) {
+  if (!d) return (int)set_error(CC_ERR_INVALID_ARG, "cc_detector_graph_active: null detector");
+  return d->last_call_graph;
 }
 
 cc_status cc_detector_set_profiling(cc_detector* d, int enabled) {

@@ -277,6 +277,10 @@ class CascadeClassifier:
     def specialized_stages(self) -> int:
         return L.lib().cc_detector_specialized_stages(self._detector())
 
+    def graph_active(self) -> bool:
+        """True if the last single-image detectMultiScale call was one hipGraph launch (cc_detector_graph_active)."""
+        return L.lib().cc_detector_graph_active(self._detector()) == 1
+
     def set_profiling(self, on: bool):
         L.check(L.lib().cc_detector_set_profiling(self._detector(), 1 if on else 0))
 

@@ -213,6 +213,11 @@ typedef struct cc_detector_timings {
 } cc_detector_timings;
 CC_API cc_status cc_detector_set_profiling(cc_detector* d, int enabled);
 CC_API cc_status cc_detector_get_timings(cc_detector* d, cc_detector_timings* t, int reset);
+/* Single-image calls (cc_detect_multiscale on a host image; the call shape of tools/detection/Cpp/main.cpp:45) replay
+ * the whole device pass from one hipGraph once a first ordinary call has sized the buffers. Returns 1 if the LAST such
+ * call was a graph launch, 0 if it used ordinary launches (first call, changed geometry, graphs switched off, or a
+ * capture that did not come out: then the detector stays on ordinary launches), negative cc_status on a null handle. */
+CC_API int cc_detector_graph_active(const cc_detector* d);
 
 /* ============================================================================================
  * 3. Building blocks exposed for parity tests and roofline measurement (all run on the device).

@@ -202,3 +202,36 @@ def test_candidate_list_overflow_in_a_multi_pass_batch(monkeypatch):
                 b = want[i][np.lexsort(want[i].T[::-1])]
                 assert a.shape == b.shape and (a == b).all(), (mb, i)
     os.unlink(path)
+
+
+def test_single_image_calls_run_from_a_hipgraph(haar_xml, monkeypatch, capfd):
+    """The tool's call shape (one host image per call) is launch-bound: after a first ordinary call has sized the buffers
+    the pass is captured and replayed as ONE graph launch. cc_detector_graph_active reports it; a capture that fails
+    falls back to ordinary launches, says so once, and returns the same rectangles."""
+    img = _faces(frame_natural(640, 480, 77), 77)
+    want = orc.detect_multiscale(orc.load_cascade_xml(haar_xml), img, 1.1, 3, nthreads=8)
+    p = cc.CascadeClassifier(haar_xml)
+    a = p.detectMultiScale(img, 1.1, 3)
+    assert not p.graph_active()  # first call: ordinary launches, buffers get their sizes
+    b = p.detectMultiScale(img, 1.1, 3)
+    assert p.graph_active()      # captured and launched as a graph
+    c = p.detectMultiScale(img, 1.1, 3)
+    assert p.graph_active()      # replayed
+    for r in (a, b, c):
+        assert r.shape == want.shape and (r == want).all()
+    other = _faces(frame_natural(640, 480, 78), 78)
+    d = p.detectMultiScale(other, 1.1, 3)  # same geometry, other pixels: still the graph
+    assert p.graph_active()
+    w2 = orc.detect_multiscale(orc.load_cascade_xml(haar_xml), other, 1.1, 3, nthreads=8)
+    assert d.shape == w2.shape and (d == w2).all()
+    p.detectMultiScale(img[:300, :400], 1.1, 3)  # new geometry: a new plan starts with an ordinary call
+    assert not p.graph_active()
+    # forced capture failure: identical rectangles from ordinary launches, one line on stderr
+    monkeypatch.setenv("CCAMD_DEBUG_FAIL_CAPTURE", "1")
+    q = cc.CascadeClassifier(haar_xml)
+    capfd.readouterr()
+    for _ in range(3):
+        r = q.detectMultiScale(img, 1.1, 3)
+        assert not q.graph_active()
+        assert r.shape == want.shape and (r == want).all()
+    assert capfd.readouterr().err.count("hipGraph capture of the single-image pass failed") == 1

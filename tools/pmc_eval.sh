@@ -21,7 +21,10 @@ for k,v in agg.items():
         import json
         cus, simds = 256, 1024
         cyc = m["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
-        out = {"kernel": k, "counters_per_launch": {c: round(x) for c, x in m.items()},
+        import os, sys
+        sys.path.insert(0, os.getcwd())
+        from bench import kernel_source_sha16
+        out = {"kernel": k, "kernel_src_sha16": kernel_source_sha16(), "counters_per_launch": {c: round(x) for c, x in m.items()},
                "kernel_cycles": round(cyc), "lds_pipeline_busy": round(m["SQ_LDS_IDX_ACTIVE"] / cus / cyc, 3),
                "lds_bank_conflict_share": round(m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"], 3),
                "valu_busy": round(m["SQ_INSTS_VALU"] * 4 / simds / cyc, 3),

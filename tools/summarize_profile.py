@@ -31,5 +31,19 @@ try:
     summary["bench"] = json.loads(open(f"{src}/bench_plain.json").read().strip().splitlines()[-1])
 except Exception as e:  # noqa: BLE001
     summary["bench_error"] = str(e)
+# HBM traffic of the cascade kernel, with the identity of the kernel sources it was measured on (bench.py replays the
+# figure only for the same sources). FETCH_SIZE counts 64 B per 128-B request on gfx950 (x2), WRITE_SIZE is exact.
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha16  # noqa: E402
+summary["kernel_src_sha16"] = kernel_source_sha16()
+for k, v in summary["kernels"].items():
+    if k.startswith("k_eval") and "FETCH_SIZE_KB_per_launch_raw" in v and "WRITE_SIZE_KB_per_launch_raw" in v and "bench" in summary:
+        fpl = summary["bench"]["roofline"]["frames_per_launch"]
+        json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_bench.sh {tag}), MI355X, bench.py "
+                             "--cpu-frames 0 --steps 2 --warmup 1, CCAMD_NO_FRONT_OVERLAP=1 (counters are device-wide)",
+                   "kernel": k, "kernel_src_sha16": summary["kernel_src_sha16"], "frames_per_launch": fpl, "fetch_correction": 2.0,
+                   "fetch_size_kb_raw_per_launch": v["FETCH_SIZE_KB_per_launch_raw"], "write_size_kb_raw_per_launch": v["WRITE_SIZE_KB_per_launch_raw"],
+                   "hbm_bytes_per_frame": (2.0 * v["FETCH_SIZE_KB_per_launch_raw"] + v["WRITE_SIZE_KB_per_launch_raw"]) * 1024 / fpl},
+                  open("profiles/r02_traffic_k_eval.json", "w"), indent=1)
 json.dump(summary, open(f"profiles/{dst_prefix}_summary.json", "w"), indent=1)
 print(json.dumps(summary["kernels"], indent=1))
