@@ -23,34 +23,52 @@
 #define CC_RECT "rect"
 #define CV_HAAR_FEATURE_MAX 3
 
-// traincascade_features.h:131-144 (the CvParams read/scanAttr/print machinery is trainer plumbing, out of scope)
-class CvFeatureParams {
+#define CC_FEATURE_PARAMS "featureParams"  // cascadeclassifier.h:58
+#define HFP_NAME "haarFeatureParams"       // haarfeatures.h:21
+#define LBPF_NAME "lbpFeatureParams"       // lbpfeatures.h:18
+
+// traincascade_features.h:105-122, features.cpp:27-32: the polymorphic base every parameter struct of the trainer derives
+// from (the driver iterates them for params.xml and the command line: traincascade.cpp:59-81,141, cascadeclassifier.cpp:200,359-400)
+class CvParams {
+ public:
+  CvParams();
+  virtual ~CvParams() {}
+  virtual void write(cv::FileStorage& fs) const = 0;
+  virtual bool read(const cv::FileNode& node) = 0;
+  virtual void printDefaults() const;
+  virtual void printAttrs() const;
+  virtual bool scanAttr(const std::string prmName, const std::string val);
+  std::string name;
+};
+
+class CvFeatureParams : public CvParams {  // traincascade_features.h:131-144, features.cpp:37-68
  public:
   enum { HAAR = 0, LBP = 1, HOG = 2 };
-  CvFeatureParams() : maxCatCount(0), featSize(1) {}
-  virtual ~CvFeatureParams() {}
-  virtual void init(const CvFeatureParams& fp) {
-    maxCatCount = fp.maxCatCount;
-    featSize = fp.featSize;
-  }
-  virtual void write(cv::FileStorage& fs) const;
+  CvFeatureParams();
+  virtual void init(const CvFeatureParams& fp);
+  void write(cv::FileStorage& fs) const override;
+  bool read(const cv::FileNode& node) override;
   static cv::Ptr<CvFeatureParams> create(int featureType);
   int maxCatCount;
   int featSize;
 };
 
-class CvHaarFeatureParams : public CvFeatureParams {  // haarfeatures.h:31-51
+class CvHaarFeatureParams : public CvFeatureParams {  // haarfeatures.h:31-51, haarfeatures.cpp:12-85
  public:
   enum { BASIC = 0, CORE = 1, ALL = 2 };
-  CvHaarFeatureParams() : mode(BASIC) {}
-  explicit CvHaarFeatureParams(int _mode) : mode(_mode) {}
+  CvHaarFeatureParams();
+  CvHaarFeatureParams(int _mode);
   void init(const CvFeatureParams& fp) override;
   void write(cv::FileStorage& fs) const override;
+  bool read(const cv::FileNode& node) override;
+  void printDefaults() const override;
+  void printAttrs() const override;
+  bool scanAttr(const std::string prm, const std::string val) override;
   int mode;
 };
 
 struct CvLBPFeatureParams : CvFeatureParams {  // lbpfeatures.h:22-26, lbpfeatures.cpp:9-13
-  CvLBPFeatureParams() { maxCatCount = 256; }
+  CvLBPFeatureParams();
 };
 
 class CvFeatureEvaluator {  // traincascade_features.h:155-188

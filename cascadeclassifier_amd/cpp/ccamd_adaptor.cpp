@@ -1,7 +1,9 @@
 // Implementation of the C++ host adaptor (see ccamd/traincascade_features.hpp). Everything numeric is delegated to the
 // C ABI (HIP kernels); status codes become cv::Exception like the reference's CV_Assert / CV_Error failures.
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
+#include <iostream>
 
 #include "ccamd/traincascade_features.hpp"
 
@@ -277,9 +279,28 @@ FileStorage& operator<<(FileStorage& fs, double v) { return fs.putNumber(real_te
 #endif
 
 // ---------------------------------------------------------------- params
+CvParams::CvParams() : name("params") {}  // features.cpp:27
+void CvParams::printDefaults() const { std::cout << "--" << name << "--" << std::endl; }  // features.cpp:28-29
+void CvParams::printAttrs() const {}                                                      // features.cpp:30
+bool CvParams::scanAttr(const std::string, const std::string) { return false; }           // features.cpp:31
+
+CvFeatureParams::CvFeatureParams() : maxCatCount(0), featSize(1) { name = CC_FEATURE_PARAMS; }  // features.cpp:36-39
+
+void CvFeatureParams::init(const CvFeatureParams& fp) {  // features.cpp:41-45
+  maxCatCount = fp.maxCatCount;
+  featSize = fp.featSize;
+}
+
 void CvFeatureParams::write(cv::FileStorage& fs) const {  // features.cpp:47-51
   fs << CC_MAX_CAT_COUNT << maxCatCount;
   fs << CC_FEATURE_SIZE << featSize;
+}
+
+bool CvFeatureParams::read(const cv::FileNode& node) {  // features.cpp:53-60
+  if (node.empty()) return false;
+  maxCatCount = node[CC_MAX_CAT_COUNT];
+  featSize = node[CC_FEATURE_SIZE];
+  return maxCatCount >= 0 && featSize >= 1;
 }
 
 cv::Ptr<CvFeatureParams> CvFeatureParams::create(int featureType) {  // features.cpp:62-68 (HOG: outside this path)
@@ -288,14 +309,58 @@ cv::Ptr<CvFeatureParams> CvFeatureParams::create(int featureType) {  // features
                               : cv::Ptr<CvFeatureParams>();
 }
 
+CvHaarFeatureParams::CvHaarFeatureParams() : mode(BASIC) { name = HFP_NAME; }            // haarfeatures.cpp:12-15
+CvHaarFeatureParams::CvHaarFeatureParams(int _mode) : mode(_mode) { name = HFP_NAME; }  // haarfeatures.cpp:17-20
+
 void CvHaarFeatureParams::init(const CvFeatureParams& fp) {  // haarfeatures.cpp:22-26
   CvFeatureParams::init(fp);
-  mode = static_cast<const CvHaarFeatureParams&>(fp).mode;
+  mode = dynamic_cast<const CvHaarFeatureParams&>(fp).mode;
 }
 
 void CvHaarFeatureParams::write(cv::FileStorage& fs) const {  // haarfeatures.cpp:28-36
   CvFeatureParams::write(fs);
-  fs << CC_MODE << std::string(mode == BASIC ? CC_MODE_BASIC : mode == CORE ? CC_MODE_CORE : mode == ALL ? CC_MODE_ALL : "");
+  const std::string modeStr = mode == BASIC ? CC_MODE_BASIC : mode == CORE ? CC_MODE_CORE : mode == ALL ? CC_MODE_ALL : std::string();
+  CV_Assert(!modeStr.empty());
+  fs << CC_MODE << modeStr;
+}
+
+bool CvHaarFeatureParams::read(const cv::FileNode& node) {  // haarfeatures.cpp:38-52
+  if (!CvFeatureParams::read(node)) return false;
+  cv::FileNode rnode = node[CC_MODE];
+  if (!rnode.isString()) return false;
+  std::string modeStr;
+  rnode >> modeStr;
+  mode = !modeStr.compare(CC_MODE_BASIC) ? BASIC : !modeStr.compare(CC_MODE_CORE) ? CORE : !modeStr.compare(CC_MODE_ALL) ? ALL : -1;
+  return mode >= 0;
+}
+
+void CvHaarFeatureParams::printDefaults() const {  // haarfeatures.cpp:54-59 (the unbalanced bracket is the reference's text)
+  CvFeatureParams::printDefaults();
+  std::cout << "  [-mode <" CC_MODE_BASIC << "(default) | " << CC_MODE_CORE << " | " << CC_MODE_ALL << std::endl;
+}
+
+void CvHaarFeatureParams::printAttrs() const {  // haarfeatures.cpp:61-68
+  CvFeatureParams::printAttrs();
+  const std::string mode_str = mode == BASIC ? CC_MODE_BASIC : mode == CORE ? CC_MODE_CORE : mode == ALL ? CC_MODE_ALL : "";
+  std::cout << "mode: " << mode_str << std::endl;
+}
+
+// haarfeatures.cpp:70-85. Kept as the reference has it: "-mode" is parsed (an unknown value leaves mode == -1) but the
+// function returns false either way, since the base class knows no attribute (pinned by test_features.cpp:96-106).
+bool CvHaarFeatureParams::scanAttr(const std::string prmName, const std::string val) {
+  if (!CvFeatureParams::scanAttr(prmName, val)) {
+    if (!prmName.compare("-mode")) {
+      mode = !val.compare(CC_MODE_CORE) ? CORE : !val.compare(CC_MODE_ALL) ? ALL : !val.compare(CC_MODE_BASIC) ? BASIC : -1;
+      if (mode == -1) return false;
+    }
+    return false;
+  }
+  return true;
+}
+
+CvLBPFeatureParams::CvLBPFeatureParams() {  // lbpfeatures.cpp:9-13
+  maxCatCount = 256;
+  name = LBPF_NAME;
 }
 
 // ---------------------------------------------------------------- evaluator base

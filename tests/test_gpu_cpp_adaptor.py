@@ -16,6 +16,15 @@ def test_cpp_adaptor_is_built():
     assert "libccamd_cpp.so" in out and "libcascadeclassifier_amd.so" in out and "not found" not in out
 
 
+def test_cpp_params_machinery_matches_the_reference_driver_flow():
+    """CvParams / CvFeatureParams / CvHaarFeatureParams / CvLBPFeatureParams: create -> printDefaults -> scanAttr -> printAttrs
+    -> write -> read, the way traincascade.cpp:59-149 and cascadeclassifier.cpp:200,359-401 drive them (tests/cpp/test_params.cpp;
+    no device needed)."""
+    r = subprocess.run([os.path.join(LIB, "test_params")], capture_output=True, text=True, timeout=120)
+    print(r.stdout[-2000:], r.stderr[-1000:])
+    assert r.returncode == 0 and " 0 failed" in r.stdout
+
+
 @pytest.mark.gpu
 def test_cpp_feature_tests_pass_on_the_device(haar_xml):
     r = subprocess.run([os.path.join(LIB, "test_features_parity"), haar_xml], capture_output=True, text=True, timeout=600)
