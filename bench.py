@@ -181,13 +181,34 @@ def main():
     chan_bytes = 8 if inf["feature_type"] == 0 else 4
     eval_bytes_per_frame = chan_bytes * integral_px  # every integral entry read exactly once
 
+    # N > 1: the gather of detections runs on the C ABI's own RCCL communicator (cc_comm_* / cc_gather_detections, what a
+    # C++ host uses); torch.distributed only carries the 128-byte unique id to the other ranks. The torch collective
+    # with the same protocol stays as the fallback (and is what the gloo rehearsal on a one-GPU box uses).
+    comm = None
+    gather_kind = "none (single rank)"
+    if world > 1:
+        gather_kind = f"torch.distributed all_gather ({args.backend})"
+        if args.backend == "nccl" and not os.environ.get("CCAMD_BENCH_TORCH_GATHER"):
+            from cascadeclassifier_amd.distributed import Comm
+            ok = torch.zeros(1, dtype=torch.int32, device=dev)
+            try:
+                comm = Comm.from_torch(dev_index)
+                ok += 1
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: cc_comm_create failed ({e}); gathering with torch.distributed", file=sys.stderr)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks or none
+            if int(ok.item()) == 1:
+                gather_kind = "cc_gather_detections (C ABI, RCCL ncclAllGather x2)"
+            else:
+                comm = None
+
     def step():
         if args.device_only:
             clf.run_device_only(frames.data_ptr(), (B, H, W), args.scale_factor)
             return None
         rects = clf.detect_batch(None, args.scale_factor, args.min_neighbors, device_ptr=frames.data_ptr(), shape=(B, H, W))
         if world > 1:
-            rects = gather_detections(rects, device=comm_dev)
+            rects = gather_detections(rects, device=comm_dev, comm=comm)
         return rects
 
     def sync():
@@ -282,6 +303,7 @@ def main():
             "frames_per_gpu_per_step": B,
             "frame_content": ("1/f noise (sigma 40)" if args.content == "natural" else "i.i.d. uniform noise") + " + 5 pasted face templates",
             "parallelism": f"frames sharded over {world} GPU(s); RCCL gather of detections only",
+            "gather": gather_kind,
             "timed_region": "device pipeline only" if args.device_only else
                             "pyramid+integral+cascade eval+skip filter+candidate copy-back+host grouping" + ("+RCCL gather" if world > 1 else ""),
         },

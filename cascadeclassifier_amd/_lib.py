@@ -129,6 +129,14 @@ SIGNATURES = {
     "cc_eval_presort": (_i, [_vp, _i]),
     "cc_eval_presort_range": (_i, [_vp, _i, _i, _i]),
     "cc_eval_find_best_split": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _d, _i, _i, C.POINTER(Split), _vp, _vp]),
+    "cc_shard_range": (None, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "cc_comm_unique_id": (_i, [_vp]),
+    "cc_comm_create": (_i, [_i, _i, _i, _vp, _pp]),
+    "cc_comm_destroy": (None, [_vp]),
+    "cc_comm_rank": (_i, [_vp]),
+    "cc_comm_world": (_i, [_vp]),
+    "cc_gather_detections": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "cc_gather_fetch": (_i, [_vp, _vp, _i, _vp, _i]),
     "cc_negminer_create": (_i, [_vp, _i, _pp]),
     "cc_negminer_destroy": (None, [_vp]),
     "cc_negminer_plan": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(_i), C.POINTER(C.c_int64)]),

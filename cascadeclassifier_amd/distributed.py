@@ -13,11 +13,85 @@ def shard_range(n_items: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_detections(per_frame: list[np.ndarray], device=None, group=None) -> list[np.ndarray]:
+class Comm:
+    """The C ABI's RCCL communicator (cc_comm_*, include/cascadeclassifier_amd.h section 7): what a C++ host program uses
+    for the gather of detections. from_torch() bootstraps it inside a torch.distributed job: rank 0 creates the RCCL
+    unique id and the existing process group broadcasts its 128 bytes."""
+
+    def __init__(self, device: int, rank: int, world: int, unique_id: bytes | None = None):
+        import ctypes as C
+
+        from . import _lib as L
+        self._c = C.c_void_p()
+        buf = None if unique_id is None else C.create_string_buffer(bytes(unique_id), 128)
+        L.check(L.lib().cc_comm_create(int(device), int(rank), int(world), buf, C.byref(self._c)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _lib as L
+        buf = C.create_string_buffer(128)
+        L.check(L.lib().cc_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch(cls, device_index: int, group=None):
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        dev = torch.device("cuda", device_index) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0, group=group)
+        return cls(device_index, rank, world, bytes(idt.cpu().numpy().tobytes()))
+
+    def gather_all(self, per_frame: list[np.ndarray]) -> list[np.ndarray]:
+        """cc_gather_detections: this rank's per-frame rectangle lists in, every rank's (global frame order) out."""
+        import ctypes as C
+
+        from . import _lib as L
+        counts = np.array([len(r) for r in per_frame], np.int32)
+        offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        rects = (np.concatenate([np.asarray(r, np.int32).reshape(-1, 4) for r in per_frame]) if len(per_frame) else np.zeros((0, 4), np.int32))
+        rects = np.ascontiguousarray(rects, np.int32)
+        nf, nr = C.c_int(0), C.c_int(0)
+        cap_f, cap_r = max(len(per_frame) * self.world, 1), max(len(rects) * self.world, 16)
+        out = np.empty((cap_r, 4), np.int32)
+        off = np.empty(cap_f + 1, np.int32)
+        st = L.lib().cc_gather_detections(self._c, rects.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), len(per_frame),
+                                          out.ctypes.data_as(C.c_void_p), cap_r, off.ctypes.data_as(C.c_void_p), cap_f, C.byref(nf), C.byref(nr))
+        if st == L.CC_ERR_BUFFER_TOO_SMALL:  # the collectives are done: fetch the kept result, do not gather again
+            out = np.empty((max(nr.value, 1), 4), np.int32)
+            off = np.empty(nf.value + 1, np.int32)
+            st = L.lib().cc_gather_fetch(self._c, out.ctypes.data_as(C.c_void_p), len(out), off.ctypes.data_as(C.c_void_p), nf.value)
+        L.check(st)
+        return [out[off[f]:off[f + 1]].copy() for f in range(nf.value)]
+
+    def close(self):
+        from . import _lib as L
+        if getattr(self, "_c", None):
+            L.lib().cc_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def gather_detections(per_frame: list[np.ndarray], device=None, group=None, comm: Comm | None = None) -> list[np.ndarray]:
     """per_frame: this rank's list of (k_i, 4) int32 rectangle arrays, frames in global order within the rank's shard.
     Returns the concatenation over ranks (rank order = global frame order under shard_range), on every rank.
     Two collectives: all_gather of [n_frames, n_rects] headers, then one padded all_gather of a flat int32 payload
-    (per-frame counts followed by rectangles). Payloads are KB-sized: latency-bound, so one message per rank."""
+    (per-frame counts followed by rectangles). Payloads are KB-sized: latency-bound, so one message per rank.
+    With `comm` (a Comm) the exchange is the C ABI's cc_gather_detections on RCCL; without, the same protocol on
+    torch.distributed (any backend: the CPU tests use gloo)."""
+    if comm is not None:
+        return comm.gather_all(per_frame)
     import torch
     import torch.distributed as dist
 

@@ -378,6 +378,37 @@ CC_API cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_
                                          int boost_type, int split_criteria, cc_split* out, double* per_var_quality,
                                          int32_t* per_var_point);
 
+/* ============================================================================================
+ * 7. Multi-GPU: the gather of detections (BASELINE configs[3]).
+ *    Detection shards by frame, one process per GPU, and needs no data-path collective: rank r runs cc_detect_batch on
+ *    frames [lo, hi) = cc_shard_range(n_frames, r, world). The only exchange is this gather of the per-frame rectangle
+ *    lists (a few KB per rank) over RCCL: one ncclAllGather of {frames, rectangles} headers and one padded
+ *    ncclAllGather of the payload (per-frame counts, then rectangles), so every rank ends up with all frames'
+ *    rectangles in global frame order. librccl is loaded on first use (an RCCL the process has already loaded, e.g.
+ *    PyTorch's, is reused); world == 1 needs no RCCL at all.
+ *    Bootstrap like any NCCL program: rank 0 calls cc_comm_unique_id and hands the CC_COMM_ID_BYTES bytes to the other
+ *    ranks by whatever channel the host program has (MPI_Bcast, a file, a socket, torch.distributed); every rank then
+ *    calls cc_comm_create (collective). There is no reference counterpart: the reference is single-process
+ *    (tools/detection/Cpp/main.cpp:42-45 handles one image).
+ * ============================================================================================ */
+typedef struct cc_comm cc_comm;
+#define CC_COMM_ID_BYTES 128
+CC_API void cc_shard_range(int n_items, int rank, int world, int* lo, int* hi);
+CC_API cc_status cc_comm_unique_id(void* id /* CC_COMM_ID_BYTES bytes */);
+CC_API cc_status cc_comm_create(int device, int rank, int world, const void* id /* may be NULL when world == 1 */, cc_comm** out);
+CC_API void cc_comm_destroy(cc_comm* c);
+CC_API int cc_comm_rank(const cc_comm* c);
+CC_API int cc_comm_world(const cc_comm* c);
+/* Collective over the communicator. rects / offsets: this rank's frames as cc_detect_batch returns them (offsets has
+ * n_frames + 1 entries). On return *n_frames_all / *n_rects_all hold the totals over all ranks. If the caller's buffers
+ * (out: cap_rects rectangles, offsets_out: cap_frames + 1 entries) are too small the call returns
+ * CC_ERR_BUFFER_TOO_SMALL, but only after the collectives have completed (the ranks stay in step) and with the result
+ * kept in the communicator: cc_gather_fetch copies it out later without communicating (never call the gather again on
+ * one rank alone). */
+CC_API cc_status cc_gather_detections(cc_comm* c, const cc_rect* rects, const int32_t* offsets, int n_frames, cc_rect* out,
+                                      int cap_rects, int32_t* offsets_out, int cap_frames, int* n_frames_all, int* n_rects_all);
+CC_API cc_status cc_gather_fetch(const cc_comm* c, cc_rect* out, int cap_rects, int32_t* offsets_out, int cap_frames);
+
 #ifdef __cplusplus
 }
 #endif

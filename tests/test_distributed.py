@@ -132,3 +132,66 @@ def test_sharded_split_search_gloo_world2(case):
         assert not got[0][0] and not got[1][0]
     else:
         assert got[0] == want and got[1] == want
+
+
+# ---- section 7 of the C ABI: cc_shard_range / cc_comm_* / cc_gather_detections ------------------------------------
+def test_c_abi_shard_range_matches_python():
+    import ctypes as C
+
+    from cascadeclassifier_amd import _lib as L
+    for n in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                lo, hi = C.c_int(-1), C.c_int(-1)
+                L.lib().cc_shard_range(n, r, world, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == shard_range(n, r, world)
+
+
+def test_c_abi_gather_single_rank_needs_no_device_and_keeps_the_result():
+    """world == 1: the gather is a copy (no RCCL, no HIP call), so the protocol's packing / unpacking and the
+    BUFFER_TOO_SMALL -> cc_gather_fetch rule are testable here."""
+    import ctypes as C
+
+    from cascadeclassifier_amd import _lib as L
+    from cascadeclassifier_amd.distributed import Comm
+    frames = [_fake_detections(f) for f in range(9)] + [np.zeros((0, 4), np.int32)]
+    comm = Comm(0, 0, 1)
+    got = gather_detections(frames, comm=comm)
+    assert len(got) == len(frames) and all(a.shape == b.shape and (a == b).all() for a, b in zip(got, frames))
+    assert gather_detections([], comm=comm) == []
+    # too-small buffers: status, totals reported, result kept for cc_gather_fetch
+    counts = np.array([len(r) for r in frames], np.int32)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    rects = np.ascontiguousarray(np.concatenate(frames), np.int32)
+    nf, nr = C.c_int(0), C.c_int(0)
+    small = np.empty((1, 4), np.int32)
+    so = np.empty(2, np.int32)
+    st = L.lib().cc_gather_detections(comm._c, rects.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), len(frames),
+                                      small.ctypes.data_as(C.c_void_p), 1, so.ctypes.data_as(C.c_void_p), 1, C.byref(nf), C.byref(nr))
+    assert st == L.CC_ERR_BUFFER_TOO_SMALL and nf.value == len(frames) and nr.value == len(rects)
+    out = np.empty((nr.value, 4), np.int32)
+    oo = np.empty(nf.value + 1, np.int32)
+    L.check(L.lib().cc_gather_fetch(comm._c, out.ctypes.data_as(C.c_void_p), nr.value, oo.ctypes.data_as(C.c_void_p), nf.value))
+    assert (oo == off).all() and (out == rects).all()
+    # argument checks
+    bad = off.copy()
+    bad[3] = bad[2] - 1
+    assert L.lib().cc_gather_detections(comm._c, rects.ctypes.data_as(C.c_void_p), bad.ctypes.data_as(C.c_void_p), len(frames), None, 0, None, 0,
+                                        C.byref(nf), C.byref(nr)) == L.CC_ERR_INVALID_ARG
+    comm.close()
+    c = C.c_void_p()
+    assert L.lib().cc_comm_create(0, 0, 2, None, C.byref(c)) == L.CC_ERR_INVALID_ARG  # more than one rank needs the unique id
+    assert L.lib().cc_comm_create(0, 3, 2, None, C.byref(c)) == L.CC_ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
+def test_c_abi_comm_bootstrap_pieces_on_the_gpu_box():
+    """RCCL resolves and hands out unique ids (the multi-rank exchange itself needs one GPU per rank: the driver's
+    8-GPU run covers it through bench.py)."""
+    from cascadeclassifier_amd.distributed import Comm
+    a, b = Comm.unique_id(), Comm.unique_id()
+    assert len(a) == 128 and a != b
+    comm = Comm(0, 0, 1, a)
+    frames = [_fake_detections(f) for f in range(5)]
+    got = gather_detections(frames, comm=comm)
+    assert all((x == y).all() for x, y in zip(got, frames))
