@@ -356,6 +356,8 @@ def main():
         }
     if rank == 0:
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
     if out.get("cpu_baseline", {}).get("rectangles_identical_to_gpu") is False:

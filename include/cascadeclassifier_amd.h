@@ -394,6 +394,7 @@ CC_API cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_
 typedef struct cc_comm cc_comm;
 #define CC_COMM_ID_BYTES 128
 CC_API void cc_shard_range(int n_items, int rank, int world, int* lo, int* hi);
+/* (An id starts RCCL's bootstrap listener: create one only for a communicator that all ranks then really build.) */
 CC_API cc_status cc_comm_unique_id(void* id /* CC_COMM_ID_BYTES bytes */);
 CC_API cc_status cc_comm_create(int device, int rank, int world, const void* id /* may be NULL when world == 1 */, cc_comm** out);
 CC_API void cc_comm_destroy(cc_comm* c);

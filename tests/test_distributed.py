@@ -184,14 +184,53 @@ def test_c_abi_gather_single_rank_needs_no_device_and_keeps_the_result():
     assert L.lib().cc_comm_create(0, 3, 2, None, C.byref(c)) == L.CC_ERR_INVALID_ARG
 
 
-@pytest.mark.gpu
-def test_c_abi_comm_bootstrap_pieces_on_the_gpu_box():
-    """RCCL resolves and hands out unique ids (the multi-rank exchange itself needs one GPU per rank: the driver's
-    8-GPU run covers it through bench.py)."""
+def _comm_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from cascadeclassifier_amd import _lib as L
     from cascadeclassifier_amd.distributed import Comm
-    a, b = Comm.unique_id(), Comm.unique_id()
-    assert len(a) == 128 and a != b
-    comm = Comm(0, 0, 1, a)
-    frames = [_fake_detections(f) for f in range(5)]
-    got = gather_detections(frames, comm=comm)
-    assert all((x == y).all() for x, y in zip(got, frames))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = Comm.from_torch(0)  # the id travels over gloo; both ranks then ask RCCL for a communicator on device 0
+    except L.CascadeError as e:
+        q.put((rank, "refused", str(e)))
+    else:
+        lo, hi = shard_range(7, rank, world)
+        allr = gather_detections([_fake_detections(f) for f in range(lo, hi)], comm=comm)
+        q.put((rank, "ok", [a.tolist() for a in allr]))
+        comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_c_abi_comm_two_ranks_on_one_gpu_either_works_or_fails_loudly():
+    """Two ranks on the box's single GPU: RCCL either builds the communicator (then the gathered lists must be right)
+    or refuses duplicate devices -- in which case cc_comm_create must return an error on BOTH ranks (bench.py then falls
+    back to the torch collective), not hang. Bounded by a timeout."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        got = [q.get(timeout=180) for _ in range(2)]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    kinds = {g[1] for g in got}
+    assert len(kinds) == 1, got  # both ranks agree
+    if kinds == {"ok"}:
+        want = [_fake_detections(f).tolist() for f in range(7)]
+        assert all(g[2] == want for g in got)
+    else:
+        print("RCCL refused two ranks on one device:", got[0][2])
