@@ -100,12 +100,66 @@ struct BatchArgs {
   int feats_per_block;
   const void* feats;
   float* out;                 // [feat_end - feat_begin][n_samples]
+  int n_tiles, xcd_tiles;     // wide kernel: sample tiles, and whether the grid is laid out XCD by XCD
   int debug_nostore;          // timing experiment: skip the output stores
   int normalized;             // Haar: divide by normfactor (operator()) or not (Feature::calc)
   int use_tilted;
 };
 
 constexpr int BATCH_THREADS = 1024;  // 16 wavefronts per block: the LDS tile allows two blocks per CU = full occupancy
+
+// LDS tile [entry p][S samples], XOR-swizzled: sample s of entry p sits at word p * S + (s ^ (p & (S - 1))).
+// Staging writes walk consecutive entries of one sample (coalesced global reads): without the swizzle all 64 lanes of a
+// store would hit one bank (stride S words); with it they spread over S banks. The evaluation reads one entry for S
+// consecutive samples: the swizzle permutes them within the same S words, still conflict-free. The feature tables hold
+// byte offsets of the swizzled entry, (p * S + (p & (S - 1))) * 4 (tilted features: plus the tilted tile's base), so that a
+// corner read is ONE xor with the lane's sample byte index: address = entry ^ (s * 4).
+__device__ __forceinline__ int batch_tile_word(int p, int s, int S) { return p * S + (s ^ (p & (min(S, 32) - 1))); }
+
+// a / b, correctly rounded, with the part that depends on b alone hoisted: operator() divides every feature value of a
+// sample by the same norm factor (haarfeatures.h:108-112). The compiler's expansion of an IEEE float division is
+//   y0 = rcp(b); y1 = fma(fma(-b, y0, 1), y0, y0); q0 = a * y1; q1 = fma(fma(-b, q0, a), y1, q0); q = fma(fma(-b, q1, a), y1, q1)
+// wrapped in v_div_scale / v_div_fmas / v_div_fixup, which rescale operands whose exponents would push an intermediate
+// into the denormal or overflow range and patch zero / infinity / NaN results; for finite normal operands far from both
+// ends (norm factors are >= 1 and < 2^21, feature sums are 0 or of magnitude >= 2^-8 and < 2^27) those three are the
+// identity, so the same five operations give the same bits. A zero dividend keeps its sign. Checked against the division
+// operator on the device over 2^32 operand pairs plus the edge values (cc_debug_division_check, tests/test_gpu_eval.py).
+__device__ __forceinline__ float refined_rcp(float b) {
+  const float y0 = __builtin_amdgcn_rcpf(b);
+  return __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+}
+__device__ __forceinline__ float div_by_refined(float a, float b, float y1) {
+  const float q0 = a * y1;
+  const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y1, q0);
+  const float q = __builtin_fmaf(__builtin_fmaf(-b, q1, a), y1, q1);
+  return a == 0.0f ? a : q;
+}
+
+// Counts operand pairs for which div_by_refined differs from the division operator (parity instrumentation).
+__global__ void k_division_check(unsigned long long seed, int per_thread, unsigned long long* mismatches) {
+  unsigned long long x = seed + (unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+  auto next = [&]() {
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    return x;
+  };
+  unsigned long long bad = 0;
+  for (int i = 0; i < per_thread; i++) {
+    const unsigned long long r = next();
+    // b: norm factors, any float in [1, 2^21); a: any float with magnitude in [2^-8, 2^27), either sign
+    const float b = __uint_as_float(0x3F800000u + (unsigned)(r % (21u << 23)));
+    const unsigned am = 0x3B800000u + (unsigned)((r >> 32) % (35u << 23));
+    const float a = __uint_as_float(am | ((unsigned)(r >> 63) << 31));
+    const float y1 = refined_rcp(b);
+    if (__float_as_uint(div_by_refined(a, b, y1)) != __float_as_uint(a / b)) bad++;
+    // integer-valued dividends (what the catalog's integer weights produce) against integer-valued and sqrt-like divisors
+    const float ai = (float)(int)((r >> 8) % 33554432u) - 16777216.0f;
+    const float bi = sqrtf((float)(1u + (unsigned)(r >> 40) % 16777215u) * (float)(1u + (unsigned)(r >> 16) % 65535u));
+    if (bi >= 1.0f && bi < 2097152.0f && __float_as_uint(div_by_refined(ai, bi, refined_rcp(bi))) != __float_as_uint(ai / bi)) bad++;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
 
 template <bool HAAR>
 __global__ __launch_bounds__(BATCH_THREADS) void k_eval_batch(BatchArgs A) {
@@ -123,8 +177,8 @@ __global__ __launch_bounds__(BATCH_THREADS) void k_eval_batch(BatchArgs A) {
       v = A.sum[(size_t)si * A.cols + p];
       if (HAAR && A.use_tilted) t = A.tilted[(size_t)si * A.cols + p];
     }
-    lsum[p * S + s] = v;
-    if (HAAR && A.use_tilted) ltil[p * S + s] = t;
+    lsum[batch_tile_word(p, s, S)] = v;
+    if (HAAR && A.use_tilted) ltil[batch_tile_word(p, s, S)] = t;
   }
   __syncthreads();
   const int s = threadIdx.x % S;
@@ -134,29 +188,159 @@ __global__ __launch_bounds__(BATCH_THREADS) void k_eval_batch(BatchArgs A) {
   if (HAAR && A.normalized && valid) nf = A.normfactor[A.sample_idx ? A.sample_idx[s0 + s] : s0 + s];
   const int f0 = A.feat_begin + blockIdx.y * A.feats_per_block;
   const int f1 = min(f0 + A.feats_per_block, A.feat_end);
-  for (int f = f0 + fsub; f < f1; f += fpar) {
-    float val;
-    if (HAAR) {
-      const HaarFeatDev F = reinterpret_cast<const HaarFeatDev*>(A.feats)[f];
-      const int32_t* img = (F.tilted ? ltil : lsum) + s;
-      float ret = F.w[0] * (float)(img[F.p[0][0]] - img[F.p[0][1]] - img[F.p[0][2]] + img[F.p[0][3]]) +
-                  F.w[1] * (float)(img[F.p[1][0]] - img[F.p[1][1]] - img[F.p[1][2]] + img[F.p[1][3]]);
-      if (F.w[2] != 0.0f) ret += F.w[2] * (float)(img[F.p[2][0]] - img[F.p[2][1]] - img[F.p[2][2]] + img[F.p[2][3]]);
-      val = A.normalized ? (nf == 0.0f ? 0.0f : ret / nf) : ret;
-    } else {
-      const LbpFeatDev F = reinterpret_cast<const LbpFeatDev*>(A.feats)[f];
-      const int32_t* b = lsum + s;
+  const char* tile = reinterpret_cast<const char*>(lds);
+  const int s4 = s * 4;
+  auto at = [&](int entry) { return *reinterpret_cast<const int32_t*>(tile + (entry ^ s4)); };
+  if (HAAR) {
+    // software pipeline: the next feature's record (a 64-byte per-lane global load) is in flight while this one is evaluated
+    const HaarFeatDev* feats = reinterpret_cast<const HaarFeatDev*>(A.feats);
+    const float y1 = refined_rcp(nf);  // the sample's norm factor does not change from feature to feature
+    HaarFeatDev F = feats[min(f0 + fsub, f1 - 1)];
+#pragma unroll 2
+    for (int f = f0 + fsub; f < f1; f += fpar) {
+      const HaarFeatDev N = feats[min(f + fpar, f1 - 1)];
+      float ret = F.w[0] * (float)(at(F.p[0][0]) - at(F.p[0][1]) - at(F.p[0][2]) + at(F.p[0][3])) +
+                  F.w[1] * (float)(at(F.p[1][0]) - at(F.p[1][1]) - at(F.p[1][2]) + at(F.p[1][3]));
+      if (F.w[2] != 0.0f) ret += F.w[2] * (float)(at(F.p[2][0]) - at(F.p[2][1]) - at(F.p[2][2]) + at(F.p[2][3]));
+      const float val = A.normalized ? (nf == 0.0f ? 0.0f : div_by_refined(ret, nf, y1)) : ret;
+      if (valid && (!A.debug_nostore || val == 12345.678f)) A.out[(size_t)(f - A.feat_begin) * A.n_samples + s0 + s] = val;
+      F = N;
+    }
+  } else {
+    const LbpFeatDev* feats = reinterpret_cast<const LbpFeatDev*>(A.feats);
+    for (int f = f0 + fsub; f < f1; f += fpar) {
+      const LbpFeatDev F = feats[f];
       int p[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) p[j] = b[F.p[j]];
+      for (int j = 0; j < 16; j++) p[j] = at(F.p[j]);
       const int c = p[5] - p[6] - p[9] + p[10];
       const int code = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
                        (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
                        (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
                        (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
-      val = (float)code;
+      const float val = (float)code;
+      if (valid && (!A.debug_nostore || val == 12345.678f)) A.out[(size_t)(f - A.feat_begin) * A.n_samples + s0 + s] = val;
     }
-    if (valid && (!A.debug_nostore || val == 12345.678f)) A.out[(size_t)(f - A.feat_begin) * A.n_samples + s0 + s] = val;
+  }
+}
+
+// Wide variant (S == 64, no tilted tile; the 24x24 BASIC / CORE / LBP shapes): a block owns a tile of 64 samples (one
+// block per CU, 160 KB of LDS) and a WAVEFRONT evaluates one feature for the 64 samples, so the feature record is
+// wave-uniform and travels through scalar loads. In the narrow kernel above every lane fetches its half-wavefront's
+// 64-byte record with vector loads: 64 lanes x 52 bytes through the texture-address path cost ~64 cycles per
+// iteration and CU, more than the arithmetic (~25) and the LDS reads (~18) together.
+__device__ __forceinline__ HaarFeatDev load_feat(const HaarFeatDev __attribute__((address_space(4)))* p) {
+  HaarFeatDev o;
+  const int __attribute__((address_space(4)))* w = (const int __attribute__((address_space(4)))*)p;
+  int* d = reinterpret_cast<int*>(&o);
+#pragma unroll
+  for (int i = 0; i < 16; i++) d[i] = w[i];
+  return o;
+}
+__device__ __forceinline__ LbpFeatDev load_feat(const LbpFeatDev __attribute__((address_space(4)))* p) {
+  LbpFeatDev o;
+  const int __attribute__((address_space(4)))* w = (const int __attribute__((address_space(4)))*)p;
+#pragma unroll
+  for (int i = 0; i < 16; i++) o.p[i] = w[i];
+  return o;
+}
+
+template <bool HAAR>
+__global__ __launch_bounds__(BATCH_THREADS) void k_eval_batch_wide(BatchArgs A) {
+  extern __shared__ int32_t lds[];  // [cols][64], swizzled like the narrow tile (S = 64: word p * 64 + (s ^ (p & 31)))
+  constexpr int S = 64;
+  // Blocks b and b + 8 run on the same XCD (round-robin dispatch): give each XCD a contiguous run of sample tiles, so that
+  // the 256-byte pieces its CUs write into a feature row are neighbours in that XCD's L2 (placement affects speed only).
+  const int tiles_per_xcd = (A.n_tiles + 7) >> 3;
+  const int tile = A.xcd_tiles ? (int)(blockIdx.x & 7) * tiles_per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (tile >= A.n_tiles) return;
+  const int s0 = tile * S;
+  {
+    // Staging: wavefront w copies samples w, w + 16, ... (4 of the 64); its lanes walk the sample's entries, 8 loads in
+    // flight per lane before the first LDS store (the tile is the first thing the block touches: nothing else hides
+    // the latency of these loads, and one CU runs one block).
+    const int lane = threadIdx.x & 63, w0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int UNROLL = 8;
+    for (int s = w0; s < S; s += BATCH_THREADS / 64) {
+      const bool in = s0 + s < A.n_samples;  // wave-uniform
+      const int si = in ? (A.sample_idx ? A.sample_idx[s0 + s] : s0 + s) : 0;
+      const int32_t* src = A.sum + (size_t)si * A.cols;
+      for (int p0 = 0; p0 < A.cols; p0 += 64 * UNROLL) {
+        int v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) {
+          const int p = p0 + k * 64 + lane;
+          v[k] = 0;
+          if (in && p < A.cols) v[k] = src[p];
+        }
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) {
+          const int p = p0 + k * 64 + lane;
+          if (p < A.cols) lds[p * S + (s ^ (p & 31))] = v[k];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int s = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool valid = s0 + s < A.n_samples;
+  float nf = 1.f;
+  if (HAAR && A.normalized && valid) nf = A.normfactor[A.sample_idx ? A.sample_idx[s0 + s] : s0 + s];
+  const int f0 = A.feat_begin + blockIdx.y * A.feats_per_block;
+  const int f1 = min(f0 + A.feats_per_block, A.feat_end);
+  // A corner read is ONE xor: LDS address = (tile base + s * 4) ^ entry. That equals base + ((s * 4) ^ entry) because the
+  // tile starts at LDS address 0 (this kernel has no static shared memory in front of its dynamic tile; checked below:
+  // any base with its low 18 bits clear would do, the tile spans less than 2^18 bytes).
+  const unsigned tile_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)lds;
+  if (tile_base & 0x3FFFFu) __builtin_trap();
+  const unsigned s4 = tile_base + (unsigned)s * 4u;
+  auto at = [&](int entry) { return *(const __attribute__((address_space(3))) int32_t*)(unsigned long long)(s4 ^ (unsigned)entry); };
+  constexpr int WAVES = BATCH_THREADS / 64;
+  float* out = A.out + s0 + s;
+  if (HAAR) {
+    const HaarFeatDev __attribute__((address_space(4)))* feats = (const HaarFeatDev __attribute__((address_space(4)))*)A.feats;
+    const float y1 = refined_rcp(nf);
+    auto eval = [&](const HaarFeatDev& F, int f) {
+      if (A.debug_nostore == 2) {  // timing experiment: the store stream alone
+        if (valid) out[(size_t)(f - A.feat_begin) * A.n_samples] = F.w[0];
+        return;
+      }
+      float ret = F.w[0] * (float)(at(F.p[0][0]) - at(F.p[0][1]) - at(F.p[0][2]) + at(F.p[0][3])) +
+                  F.w[1] * (float)(at(F.p[1][0]) - at(F.p[1][1]) - at(F.p[1][2]) + at(F.p[1][3]));
+      if (F.w[2] != 0.0f) ret += F.w[2] * (float)(at(F.p[2][0]) - at(F.p[2][1]) - at(F.p[2][2]) + at(F.p[2][3]));
+      const float val = A.normalized ? (nf == 0.0f ? 0.0f : div_by_refined(ret, nf, y1)) : ret;
+      if (valid && (A.debug_nostore != 1 || val == 12345.678f)) out[(size_t)(f - A.feat_begin) * A.n_samples] = val;
+    };
+    // Two features per trip: their records (scalar loads, wave-uniform) are requested together. Scalar loads and LDS reads
+    // share one completion counter and scalar data may return out of order, so a wavefront cannot wait for an LDS read
+    // while a scalar load is in flight without waiting for that load too: a record fetch cannot be overlapped with the
+    // evaluation of the previous feature, only amortised over more features.
+    for (int f = f0 + wave; f < f1; f += 2 * WAVES) {
+      const bool two = f + WAVES < f1;
+      const HaarFeatDev Fa = load_feat(feats + f), Fb = load_feat(feats + (two ? f + WAVES : f));
+      eval(Fa, f);
+      if (two) eval(Fb, f + WAVES);
+    }
+  } else {
+    const LbpFeatDev __attribute__((address_space(4)))* feats = (const LbpFeatDev __attribute__((address_space(4)))*)A.feats;
+    auto eval = [&](const LbpFeatDev& F, int f) {
+      int p[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) p[j] = at(F.p[j]);
+      const int c = p[5] - p[6] - p[9] + p[10];
+      const int code = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
+                       (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
+                       (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
+                       (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
+      const float val = (float)code;
+      if (valid && (!A.debug_nostore || val == 12345.678f)) out[(size_t)(f - A.feat_begin) * A.n_samples] = val;
+    };
+    for (int f = f0 + wave; f < f1; f += 2 * WAVES) {
+      const bool two = f + WAVES < f1;
+      const LbpFeatDev Fa = load_feat(feats + f), Fb = load_feat(feats + (two ? f + WAVES : f));
+      eval(Fa, f);
+      if (two) eval(Fb, f + WAVES);
+    }
   }
 }
 
@@ -273,8 +457,12 @@ __global__ void k_feature_calc_rows(const HaarFeatDev* __restrict__ feats, int n
   out[i] = ret;
 }
 
-// `mul` scales the offsets (the batch kernel's LDS tile is [entry][S samples]: entry offsets are pre-multiplied by S).
-static void haar_to_dev(const HaarFeature& f, int step, HaarFeatDev& d, int mul = 1) {
+// Byte offset of integral entry p in the batch kernel's swizzled LDS tile (see k_eval_batch), plus a base in bytes.
+static inline int batch_entry(int p, int S, int base_bytes) { return (p * S + (p & (std::min(S, 32) - 1))) * 4 + base_bytes; }
+
+// batch_S > 0: offsets for k_eval_batch (swizzled tile of batch_S samples; a tilted feature reads the tilted tile
+// `tilted_base` bytes behind the sum tile); batch_S == 0: plain entry offsets (fastRect, row stride `step`).
+static void haar_to_dev(const HaarFeature& f, int step, HaarFeatDev& d, int batch_S = 0, int tilted_base = 0) {
   std::memset(&d, 0, sizeof(d));
   d.tilted = f.tilted;
   for (int j = 0; j < 3; j++) d.w[j] = f.w[j];
@@ -292,13 +480,21 @@ static void haar_to_dev(const HaarFeature& f, int step, HaarFeatDev& d, int mul 
       d.p[j][2] = x + w + step * (y + w);
       d.p[j][3] = x + w - h + step * (y + w + h);
     }
-    for (int k = 0; k < 4; k++) d.p[j][k] *= mul;
+    if (batch_S > 0)
+      for (int k = 0; k < 4; k++) d.p[j][k] = batch_entry(d.p[j][k], batch_S, f.tilted ? tilted_base : 0);
   }
+  if (batch_S > 0)  // unused rectangles read entry 0 of their tile (value times weight 0 upstream; never added here)
+    for (int j = 0; j < 3; j++)
+      if (f.w[j] == 0.0f)
+        for (int k = 0; k < 4; k++) d.p[j][k] = batch_entry(0, batch_S, f.tilted ? tilted_base : 0);
 }
 
-static void lbp_to_dev(const int32_t* r, int step, LbpFeatDev& d, int mul = 1) {  // lbpfeatures.cpp:53-63
+static void lbp_to_dev(const int32_t* r, int step, LbpFeatDev& d, int batch_S = 0) {  // lbpfeatures.cpp:53-63
   for (int rr = 0; rr < 4; rr++)
-    for (int cc = 0; cc < 4; cc++) d.p[4 * rr + cc] = ((r[0] + cc * r[2]) + step * (r[1] + rr * r[3])) * mul;
+    for (int cc = 0; cc < 4; cc++) {
+      const int p = (r[0] + cc * r[2]) + step * (r[1] + rr * r[3]);
+      d.p[4 * rr + cc] = batch_S > 0 ? batch_entry(p, batch_S, 0) : p;
+    }
 }
 
 }  // namespace ccamd
@@ -333,17 +529,30 @@ cc_status launch_batch(cc_evaluator* e, bool haar, const void* feats, int fb, in
   A.feats = feats;
   A.out = d_out_ptr;
   A.normalized = normalized;
-  A.debug_nostore = std::getenv("CCAMD_DEBUG_EVAL_NOSTORE") ? 1 : 0;
+  A.debug_nostore = std::getenv("CCAMD_DEBUG_EVAL_NOSTORE") ? std::max(1, std::atoi(std::getenv("CCAMD_DEBUG_EVAL_NOSTORE"))) : 0;
   A.use_tilted = e->use_tilted ? 1 : 0;
   const int nfe = fe - fb;
   const int tiles = (ns + e->S - 1) / e->S;
-  // enough feature chunks to fill the chip, but each block amortises its tile load over >= 2048 features
-  int chunks = std::max(1, std::min((nfe + 2047) / 2048, std::max(1, 16384 / std::max(tiles, 1))));
+  // Feature chunks: a block stages its sample tile once per chunk and then walks the chunk's features. Enough chunks for
+  // about `rounds` rounds of blocks over the chip (balance), each amortising its tile load over >= 2048 features.
+  // Measured at 162 336 x 20 000 (ms for the whole matrix): 2 chunks per launch 7.9, 5: 7.2, 16: 6.6, 32: 7.0, 64: 8.0.
+  const int per_cu = e->S == 64 ? 1 : 2, rounds = 20;
+  int chunks = (256 * per_cu * rounds + tiles - 1) / std::max(tiles, 1);
+  chunks = std::max(1, std::min(chunks, (nfe + 2047) / 2048));
+  if (const char* v = std::getenv("CCAMD_EVAL_CHUNKS")) chunks = std::max(1, std::min(std::atoi(v), nfe));  // tuning
   A.feats_per_block = (nfe + chunks - 1) / chunks;
   chunks = (nfe + A.feats_per_block - 1) / A.feats_per_block;
   const size_t lds = (size_t)e->cols * e->S * 4 * (haar && e->use_tilted ? 2 : 1);
   (void)hipEventRecord(e->ev_a, e->stream);
-  if (haar)
+  A.n_tiles = tiles;
+  A.xcd_tiles = std::getenv("CCAMD_EVAL_NO_XCD_TILES") ? 0 : 1;
+  if (e->S == 64) {  // wide tile (cc_eval_create chose it): one feature per wavefront, scalar record loads
+    const int gx = A.xcd_tiles ? ((tiles + 7) / 8) * 8 : tiles;
+    if (haar)
+      hipLaunchKernelGGL(k_eval_batch_wide<true>, dim3(gx, chunks), dim3(BATCH_THREADS), lds, e->stream, A);
+    else
+      hipLaunchKernelGGL(k_eval_batch_wide<false>, dim3(gx, chunks), dim3(BATCH_THREADS), lds, e->stream, A);
+  } else if (haar)
     hipLaunchKernelGGL(k_eval_batch<true>, dim3(tiles, chunks), dim3(BATCH_THREADS), lds, e->stream, A);
   else
     hipLaunchKernelGGL(k_eval_batch<false>, dim3(tiles, chunks), dim3(BATCH_THREADS), lds, e->stream, A);
@@ -370,6 +579,27 @@ static cc_status upload_indices(cc_evaluator* e, const int32_t* sample_idx, int 
 }  // namespace ccamd
 
 extern "C" {
+
+cc_status cc_debug_division_check(int device, uint64_t n_pairs, uint64_t seed, uint64_t* mismatches) {
+  if (!mismatches) return set_error(CC_ERR_INVALID_ARG, "cc_debug_division_check: null output");
+  int n = 0;
+  hipError_t err = hipGetDeviceCount(&n);
+  if (err != hipSuccess || n <= 0) return set_error(CC_ERR_NO_DEVICE, "no usable HIP device; this library has no CPU fallback");
+  if (device < 0 || device >= n) return set_error(CC_ERR_INVALID_ARG, "device %d out of range (devices: %d)", device, n);
+  CC_HIP(hipSetDevice(device));
+  unsigned long long* d = nullptr;
+  CC_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned long long)));
+  CC_HIP(hipMemset(d, 0, sizeof(unsigned long long)));
+  const int threads = 256, blocks = 4096;
+  const int per_thread = (int)std::max<uint64_t>(1, std::min<uint64_t>((n_pairs + (uint64_t)threads * blocks - 1) / ((uint64_t)threads * blocks), 1u << 20));
+  hipLaunchKernelGGL(k_division_check, dim3(blocks), dim3(threads), 0, 0, (unsigned long long)seed, per_thread, d);
+  unsigned long long h = 0;
+  const hipError_t e2 = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e2 != hipSuccess) return set_error(CC_ERR_HIP, "cc_debug_division_check: %s", hipGetErrorString(e2));
+  *mismatches = h;
+  return CC_OK;
+}
 
 cc_status cc_eval_create(int feature_type, int haar_mode, int win_w, int win_h, int max_samples, int device, cc_evaluator** out) {
   if (!out) return set_error(CC_ERR_INVALID_ARG, "cc_eval_create: null output");
@@ -400,10 +630,14 @@ cc_status cc_eval_create(int feature_type, int haar_mode, int win_w, int win_h, 
   int S = 32;
   while (S > 1 && per_sample * S > budget) S >>= 1;
   if (per_sample * S > budget) return set_error(CC_ERR_UNSUPPORTED, "cc_eval_create: window %dx%d too large for the LDS tile", win_w, win_h);
+  // the wide tile (64 samples, the whole 160 KB of a CU, k_eval_batch_wide) where it fits and no tilted tile is needed
+  if (!e->use_tilted && per_sample * 64 <= 160 * 1024 && !std::getenv("CCAMD_EVAL_NARROW_TILE")) S = 64;
   e->S = S;
   if (per_sample * S > 64 * 1024) {
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_batch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_sample * S)));
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_sample * S)));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_batch_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_sample * S)));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_batch_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_sample * S)));
   }
   CC_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   CC_HIP(hipEventCreate(&e->ev_a));
@@ -420,7 +654,7 @@ cc_status cc_eval_create(int feature_type, int haar_mode, int win_w, int win_h, 
     haar_catalog(win_w, win_h, haar_mode, e->haar);
     e->nfeat = (int)e->haar.size();
     std::vector<HaarFeatDev> dev(e->haar.size());
-    for (size_t i = 0; i < dev.size(); i++) haar_to_dev(e->haar[i], win_w + 1, dev[i], e->S);
+    for (size_t i = 0; i < dev.size(); i++) haar_to_dev(e->haar[i], win_w + 1, dev[i], e->S, e->use_tilted ? e->cols * e->S * 4 : 0);
     CC_HIP(e->d_haar.ensure(std::max<size_t>(dev.size(), 1)));
     CC_HIP(hipMemcpy(e->d_haar.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice));
   } else {
@@ -608,7 +842,7 @@ cc_status cc_eval_calc_custom_haar(cc_evaluator* e, const cc_haar_feature* feats
       ok = ok && (f.tilted ? (x - h >= 0 && x + w <= e->W && y + w + h <= e->H) : (x + w <= e->W && y + h <= e->H));
       if (!ok) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc_custom_haar: rect %d of feature %d leaves the window", j, i);
     }
-    haar_to_dev(f, e->W + 1, dev[i], e->S);
+    haar_to_dev(f, e->W + 1, dev[i], e->S, e->use_tilted ? e->cols * e->S * 4 : 0);
   }
   std::lock_guard<std::mutex> lk(e->mu);
   const int32_t* d_idx = nullptr;

@@ -234,6 +234,11 @@ CC_API cc_status cc_resize_linear_exact_u8(int device, const uint8_t* src, int s
  * 64 consecutive lanes) so that the FETCH_SIZE counter can be calibrated on a known byte count
  * (MI355X_MICROARCH.md, HBM section). *checksum receives the wrapped 32-bit sum of the words read. */
 CC_API cc_status cc_debug_stream_dwords(int device, size_t n_bytes, int repeats, uint32_t* checksum);
+/* Parity instrumentation: the bulk evaluator divides by a sample's norm factor with the operand-independent half of the
+ * IEEE division hoisted out of the feature loop (cc_eval.hip: div_by_refined). Compares it with the division operator
+ * on the device for n_pairs pseudo-random operand pairs of the evaluator's value ranges (x2: arbitrary floats and
+ * integer-valued dividends over sqrt-shaped divisors); *mismatches must come back 0. */
+CC_API cc_status cc_debug_division_check(int device, uint64_t n_pairs, uint64_t seed, uint64_t* mismatches);
 /* Host-side (tiny, serial in the reference too): cv::groupRectangles(rects, group_threshold, eps). */
 CC_API cc_status cc_group_rectangles(const cc_rect* rects, int n, int group_threshold, double eps, cc_rect* out, int cap,
                                      int* n_out);

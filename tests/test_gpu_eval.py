@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import cascadeclassifier_amd as cc
+from cascadeclassifier_amd import _lib as L
 from cascadeclassifier_amd import evaluator as ev
 from oracle import oracle as orc
 from tests.util import read_vec
@@ -291,3 +292,13 @@ def test_operator_call_is_safe_for_concurrent_callers():
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_hoisted_division_is_the_division_operator():
+    """operator() divides by the sample's norm factor (haarfeatures.h:108-112); the bulk kernel hoists the half of the
+    IEEE division that depends on the divisor alone. 2^32 operand pairs of the evaluator's ranges, compared bit for bit
+    with `a / b` on the device: no mismatch."""
+    import ctypes as C
+    bad = C.c_uint64(123)
+    L.check(L.lib().cc_debug_division_check(0, 1 << 32, 20261004, C.byref(bad)))
+    assert bad.value == 0
