@@ -513,6 +513,91 @@ __global__ __launch_bounds__(256) void k_negmine_windows(MineArgs A) {
   A.pass[i] = pass;
 }
 
+// Same stream, one WAVEFRONT per window: the 64 lanes take the stumps of a stage (stump t = first + lane, + 64, ...), their
+// votes meet in a DPP wave sum. A background image yields only ~10^4 stream windows (13 584 for 1920x1080): one thread per
+// window leaves most of the chip idle while a few hundred threads walk every stage serially. Used for stump cascades whose
+// stage sums are exact in double whatever the order (stage_sums_order_independent), so the parallel sum equals the
+// trainer's sequential one bit for bit; other cascades keep k_negmine_windows.
+template <bool HAAR>
+__global__ __launch_bounds__(256) void k_negmine_wave(MineArgs A) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (i >= A.n_windows) return;  // wave-uniform
+  int l = 0;
+  while (l + 1 < A.n_levels && A.levels[l + 1].win_first <= i) l++;
+  const MineLevel L = A.levels[l];
+  const int k = (int)(i - L.win_first);
+  const int gy = k / L.nx, gx = k - gy * L.nx;
+  const int x = A.ox + gx * A.sx, y = A.oy + gy * A.sy;
+  const int32_t* sum = A.integ + L.int_ofs;
+  const int32_t* til = A.integ + 2 * A.chan_elems + L.int_ofs;
+  const int P = L.pitchI;
+  const size_t base = (size_t)y * P + x;
+  float nf = 1.f;
+  if (HAAR) {
+    const unsigned* sq = reinterpret_cast<const unsigned*>(A.integ + A.chan_elems + L.int_ofs);
+    const int nw = A.W0 - 2, nh = A.H0 - 2;
+    const size_t q = base + P + 1;
+    const int vs = sum[q] - sum[q + nw] - sum[q + (size_t)nh * P] + sum[q + (size_t)nh * P + nw];
+    const unsigned vq = sq[q] - sq[q + nw] - sq[q + (size_t)nh * P] + sq[q + (size_t)nh * P + nw];
+    const double area = (double)(nw * nh);
+    nf = (float)sqrt((double)(area * (double)vq - (double)vs * (double)vs));
+  }
+  uint8_t pass = 1;
+  for (int st = 0; st < A.nstages; st++) {
+    const int first = A.stage_first[st], nt = A.stage_ntrees[st];
+    double part = 0;
+    for (int t = first + lane; t < first + nt; t += 64) {
+      const MineNode* n = A.nodes + A.tree_root[t];
+      bool go_left;
+      if (HAAR) {
+        const int32_t* b = (n->tilted ? til : sum) + base;
+        float ret = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          if (j == 2 && n->w[2] == 0.0f) break;
+          const int rx = n->r[j][0], ry = n->r[j][1], rw = n->r[j][2], rh = n->r[j][3];
+          int p0, p1, p2, p3;
+          if (!n->tilted) {
+            p0 = rx + P * ry;
+            p1 = rx + rw + P * ry;
+            p2 = rx + P * (ry + rh);
+            p3 = rx + rw + P * (ry + rh);
+          } else {
+            p0 = rx + P * ry;
+            p1 = rx - rh + P * (ry + rh);
+            p2 = rx + rw + P * (ry + rw);
+            p3 = rx + rw - rh + P * (ry + rw + rh);
+          }
+          const float term = n->w[j] * (float)(b[p0] - b[p1] - b[p2] + b[p3]);
+          ret = j == 0 ? term : ret + term;
+        }
+        const float val = nf == 0.0f ? 0.0f : ret / nf;
+        go_left = val <= n->thr;
+      } else {
+        const int32_t* b = sum + base;
+        int p[16];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++) p[4 * rr + cc] = b[(n->r[0][0] + cc * n->r[0][2]) + P * (n->r[0][1] + rr * n->r[0][3])];
+        const int c = p[5] - p[6] - p[9] + p[10];
+        const int code = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
+                         (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
+                         (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
+                         (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
+        go_left = (n->subset[code >> 5] & (1 << (code & 31))) != 0;
+      }
+      part += (double)A.leaves[A.tree_leaf0[t] - (go_left ? n->left : n->right)];
+    }
+    if (wave_sum_f64(part) < (double)A.stage_thr[st]) {
+      pass = 0;
+      break;
+    }
+  }
+  if (lane == 0) A.pass[i] = pass;
+}
+
 // copies the pixels of selected stream windows out of the ladder: one block per window
 __global__ __launch_bounds__(64) void k_negmine_gather(const uint8_t* __restrict__ pyr, const MineLevel* __restrict__ levels, int n_levels,
                                                        const long long* __restrict__ keep, int W0, int H0, int ox, int oy, int sx, int sy,
@@ -2669,11 +2754,21 @@ cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int he
   A.leaves = m->d_leaves.p;
   A.pass = m->d_pass.p;
   if (wins > 0) {
-    const unsigned nb = (unsigned)((wins + 255) / 256);
-    if (haar)
-      hipLaunchKernelGGL(k_negmine_windows<true>, dim3(nb), dim3(256), 0, s, A);
-    else
-      hipLaunchKernelGGL(k_negmine_windows<false>, dim3(nb), dim3(256), 0, s, A);
+    // one wavefront per window where the parallel stage sum is exact (stumps, order-independent sums); else one thread per window
+    const bool wave_mode = M.max_nodes_per_tree == 1 && stage_sums_order_independent(M) && !std::getenv("CCAMD_NEGMINE_THREAD_PER_WINDOW");
+    if (wave_mode) {
+      const unsigned nb = (unsigned)((wins + 3) / 4);
+      if (haar)
+        hipLaunchKernelGGL(k_negmine_wave<true>, dim3(nb), dim3(256), 0, s, A);
+      else
+        hipLaunchKernelGGL(k_negmine_wave<false>, dim3(nb), dim3(256), 0, s, A);
+    } else {
+      const unsigned nb = (unsigned)((wins + 255) / 256);
+      if (haar)
+        hipLaunchKernelGGL(k_negmine_windows<true>, dim3(nb), dim3(256), 0, s, A);
+      else
+        hipLaunchKernelGGL(k_negmine_windows<false>, dim3(nb), dim3(256), 0, s, A);
+    }
   }
   CC_HIP(hipGetLastError());
   if (wins > 0) CC_HIP(hipMemcpyAsync(pass, m->d_pass.p, (size_t)wins, hipMemcpyDeviceToHost, s));
