@@ -120,6 +120,7 @@ SIGNATURES = {
     "cc_eval_set_images": (_i, [_vp, _vp, _i, _i, _vp]),
     "cc_eval_labels": (C.POINTER(C.c_float), [_vp]),
     "cc_eval_calc": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
+    "cc_eval_calc_list": (_i, [_vp, _vp, _i, _i, _vp]),
     "cc_eval_calc_batch": (_i, [_vp, _i, _i, _vp, _i, _vp, _i]),
     "cc_eval_calc_batch_sorted": (_i, [_vp, _i, _i, _i, _vp, _vp, _i]),
     "cc_eval_calc_custom_haar": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),

@@ -5,6 +5,7 @@
 // keeps owning a cv::Ptr<CvFeatureEvaluator>, CvCascadeBoostTrainData keeps calling operator()(featureIdx, sampleIdx).
 #pragma once
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -102,7 +103,10 @@ class CvFeatureEvaluator {  // traincascade_features.h:155-188
   void presort(int nSamples) const;
   cc_split findBestSplit(const int* sampleIdx, int n, const double* subtreeWeights, const float* ordResponses,
                          const int* classLabels, double nodeValue, int boostType, int splitCriteria) const;
-  cc_evaluator* handle() const { return h; }
+  cc_evaluator* handle() const {  // for direct C-ABI calls: queued setImage() calls are sent first
+    flushImages();
+    return h;
+  }
 
  protected:
   virtual void generateFeatures() = 0;
@@ -117,7 +121,15 @@ class CvFeatureEvaluator {  // traincascade_features.h:155-188
   cv::Mat cls;
   cc_evaluator* h;
   int maxSampleCount;
-  unsigned generation;  // bumped by every setImage: invalidates cached feature rows
+  unsigned generation;  // bumped by every setImage: invalidates cached feature values
+  unsigned long long uid;  // unique per init(): the per-thread value caches belong to one initialised evaluator
+
+  // setImage() calls are queued on the host and reach the device as ONE cc_eval_set_images per run of consecutive
+  // indices, when something first reads (the positives / negatives of a stage are set one by one:
+  // cascadeclassifier.cpp:329-357). Guarded by a mutex: operator() is const and called from parallel_for_ workers.
+  void flushImages() const;
+  struct Pending;
+  mutable Pending* pending;
 };
 
 class CvHaarEvaluator : public CvFeatureEvaluator {  // haarfeatures.h:61-106

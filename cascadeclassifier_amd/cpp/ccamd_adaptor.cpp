@@ -1,5 +1,6 @@
 // Implementation of the C++ host adaptor (see ccamd/traincascade_features.hpp). Everything numeric is delegated to the
 // C ABI (HIP kernels); status codes become cv::Exception like the reference's CV_Assert / CV_Error failures.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -16,14 +17,28 @@ inline void check(cc_status st, const char* where) {
   if (st != CC_OK) throw_last(where);
 }
 
-// per-thread cache of one feature row: operator()(fi, si) for si = 0..N-1 costs one device evaluation per feature
-struct RowCache {
-  const void* owner = nullptr;
+// Per-thread caches behind the scalar operator()(fi, si). The trainer calls it in two shapes:
+//  * one feature over many samples (precalculate, get_ord_var_data: o_cvcascadeboosttraindata.cpp:403-458,490-596):
+//    a miss evaluates the whole ROW fi on the device (one launch per feature);
+//  * many features of one freshly set sample (stage prediction during negative mining: cascadeclassifier.cpp:340-347 ->
+//    boost.cpp:461-477 -> getVarValue): the features asked for are the cascade's, the same list window after window. The
+//    cache learns that list and a miss evaluates the whole list for the sample in ONE launch (cc_eval_calc_list), so a
+//    window costs one device evaluation instead of one per weak classifier.
+// Which shape a miss belongs to is read off the previous miss: same sample, other feature -> list shape.
+struct ValueCache {
+  unsigned long long owner = 0;  // uid of the evaluator the cached values and the learned list belong to
   unsigned generation = 0;
-  int fi = -1;
+  int row_fi = -1;  // row cache
   std::vector<float> row;
+  int col_si = -1;  // list ("column") cache
+  std::vector<int32_t> list;  // learned feature list, in first-seen order
+  std::vector<int32_t> slot;  // feature index -> position in `list` (-1 = not in it), sized on first use
+  std::vector<float> col;
+  int last_fi = -1, last_si = -1;  // previous miss
 };
-thread_local RowCache g_row;
+thread_local ValueCache g_cache;
+std::atomic<unsigned long long> g_next_uid{1};
+constexpr size_t kMaxLearnedFeatures = 16384;
 
 }  // namespace
 
@@ -364,10 +379,17 @@ CvLBPFeatureParams::CvLBPFeatureParams() {  // lbpfeatures.cpp:9-13
 }
 
 // ---------------------------------------------------------------- evaluator base
+struct CvFeatureEvaluator::Pending {
+  std::mutex mu;
+  int first = -1, n = 0;
+  std::vector<uchar> pixels, labels;
+};
+
 CvFeatureEvaluator::CvFeatureEvaluator()
-    : npos(0), nneg(0), numFeatures(0), featureParams(nullptr), h(nullptr), maxSampleCount(0), generation(0) {}
+    : npos(0), nneg(0), numFeatures(0), featureParams(nullptr), h(nullptr), maxSampleCount(0), generation(0), uid(0), pending(nullptr) {}
 
 CvFeatureEvaluator::~CvFeatureEvaluator() {
+  delete pending;
   if (h) cc_eval_destroy(h);
 }
 
@@ -381,6 +403,7 @@ void CvFeatureEvaluator::init(const CvFeatureParams* _featureParams, int _maxSam
     cc_eval_destroy(h);
     h = nullptr;
   }
+  if (pending) pending->n = 0;  // images queued for the previous evaluator go with it
   check(cc_eval_create(featureType(), haarMode(), winSize.width, winSize.height, _maxSampleCount, /*device=*/0, &h),
         "CvFeatureEvaluator::init");
   // `cls` is a header over the library's host label array: CvCascadeBoostTrainData wraps it without copying
@@ -388,29 +411,62 @@ void CvFeatureEvaluator::init(const CvFeatureParams* _featureParams, int _maxSam
   cls = cv::Mat(_maxSampleCount, 1, CV_32FC1, const_cast<float*>(cc_eval_labels(h)));
   generateFeatures();
   generation++;
+  uid = g_next_uid.fetch_add(1);
 }
 
 void CvFeatureEvaluator::setImage(const cv::Mat& img, uchar clsLabel, int idx) {
   CV_Assert(img.cols == winSize.width);  // features.cpp:85-87
   CV_Assert(img.rows == winSize.height);
-  CV_Assert(idx < cls.rows);
-  check(cc_eval_set_image(h, img.data, img.step, clsLabel, idx), "CvFeatureEvaluator::setImage");
+  CV_Assert(idx >= 0 && idx < cls.rows);
+  CV_Assert(img.type() == CV_8UC1);
+  if (!pending) pending = new Pending;
+  {
+    std::lock_guard<std::mutex> lk(pending->mu);
+    if (pending->n > 0 && idx != pending->first + pending->n) {  // not the next index of the run: send the run first
+      check(cc_eval_set_images(h, pending->pixels.data(), pending->n, pending->first, pending->labels.data()), "CvFeatureEvaluator::setImage");
+      pending->n = 0;
+    }
+    if (pending->n == 0) {
+      pending->first = idx;
+      pending->pixels.clear();
+      pending->labels.clear();
+    }
+    for (int y = 0; y < img.rows; y++) pending->pixels.insert(pending->pixels.end(), img.ptr<uchar>(y), img.ptr<uchar>(y) + img.cols);
+    pending->labels.push_back(clsLabel);
+    pending->n++;
+  }
+  cls.at<float>(idx, 0) = (float)clsLabel;  // getCls() answers from host memory at once (features.cpp:88)
   generation++;
 }
 
+void CvFeatureEvaluator::flushImages() const {
+  if (!pending) return;
+  std::lock_guard<std::mutex> lk(pending->mu);
+  if (pending->n == 0) return;
+  const int n = pending->n;
+  pending->n = 0;
+  check(cc_eval_set_images(h, pending->pixels.data(), n, pending->first, pending->labels.data()), "CvFeatureEvaluator::setImage");
+}
+
 void CvFeatureEvaluator::setImages(const uchar* imgs, int n, int first_idx, const uchar* labels) {
+  flushImages();
   check(cc_eval_set_images(h, imgs, n, first_idx, labels), "CvFeatureEvaluator::setImages");
   generation++;
 }
 
 void CvFeatureEvaluator::calcBatch(int fiBegin, int fiEnd, const int* sampleIdx, int nSamples, float* out) const {
+  flushImages();
   check(cc_eval_calc_batch(h, fiBegin, fiEnd, sampleIdx, nSamples, out, 0), "CvFeatureEvaluator::calcBatch");
 }
 
-void CvFeatureEvaluator::presort(int nSamples) const { check(cc_eval_presort(h, nSamples), "CvFeatureEvaluator::presort"); }
+void CvFeatureEvaluator::presort(int nSamples) const {
+  flushImages();
+  check(cc_eval_presort(h, nSamples), "CvFeatureEvaluator::presort");
+}
 
 cc_split CvFeatureEvaluator::findBestSplit(const int* sampleIdx, int n, const double* subtreeWeights, const float* ordResponses,
                                            const int* classLabels, double nodeValue, int boostType, int splitCriteria) const {
+  flushImages();
   cc_split sp;
   check(cc_eval_find_best_split(h, sampleIdx, n, subtreeWeights, ordResponses, classLabels, nodeValue, boostType, splitCriteria, &sp,
                                 nullptr, nullptr),
@@ -419,20 +475,51 @@ cc_split CvFeatureEvaluator::findBestSplit(const int* sampleIdx, int n, const do
 }
 
 void CvFeatureEvaluator::calcBatchSorted(int fiBegin, int fiEnd, int nSamples, float* vals, void* sortedIdx, bool idx16) const {
+  flushImages();
   check(cc_eval_calc_batch_sorted(h, fiBegin, fiEnd, nSamples, vals, sortedIdx, idx16 ? 2 : 4), "CvFeatureEvaluator::calcBatchSorted");
 }
 
 float CvFeatureEvaluator::cachedValue(int featureIdx, int sampleIdx) const {
-  RowCache& rc = g_row;
-  if (rc.owner != this || rc.generation != generation || rc.fi != featureIdx) {
-    rc.row.resize((size_t)maxSampleCount);
-    check(cc_eval_calc_batch(h, featureIdx, featureIdx + 1, nullptr, maxSampleCount, rc.row.data(), 0), "CvFeatureEvaluator::operator()");
-    rc.owner = this;
-    rc.generation = generation;
-    rc.fi = featureIdx;
-  }
   CV_Assert(sampleIdx >= 0 && sampleIdx < maxSampleCount);
-  return rc.row[(size_t)sampleIdx];
+  CV_Assert(featureIdx >= 0 && featureIdx < numFeatures);
+  ValueCache& c = g_cache;
+  if (c.owner != uid) {  // another evaluator used this thread before: forget everything, including the learned list
+    c = ValueCache();
+    c.owner = uid;
+    c.generation = generation;
+  }
+  if (c.generation != generation) {  // samples changed: values are stale, the learned list is not
+    c.generation = generation;
+    c.row_fi = -1;
+    c.col_si = -1;
+  }
+  if (c.row_fi == featureIdx) return c.row[(size_t)sampleIdx];
+  if (c.col_si == sampleIdx && !c.slot.empty() && c.slot[(size_t)featureIdx] >= 0) return c.col[(size_t)c.slot[(size_t)featureIdx]];
+  flushImages();
+  const bool list_shape = c.last_si == sampleIdx && c.last_fi != featureIdx && c.last_fi >= 0;
+  auto learn = [&](int fi) {
+    if (c.slot.empty()) c.slot.assign((size_t)numFeatures, -1);
+    if (c.slot[(size_t)fi] < 0 && c.list.size() < kMaxLearnedFeatures) {
+      c.slot[(size_t)fi] = (int32_t)c.list.size();
+      c.list.push_back(fi);
+    }
+  };
+  c.last_fi = featureIdx;
+  c.last_si = sampleIdx;
+  if (list_shape) {
+    learn(featureIdx);
+    if (c.slot[(size_t)featureIdx] >= 0) {
+      c.col.resize(c.list.size());
+      check(cc_eval_calc_list(h, c.list.data(), (int)c.list.size(), sampleIdx, c.col.data()), "CvFeatureEvaluator::operator()");
+      c.col_si = sampleIdx;
+      return c.col[(size_t)c.slot[(size_t)featureIdx]];
+    }
+  }
+  learn(featureIdx);  // a later list-shaped miss evaluates this feature along with the others
+  c.row.resize((size_t)maxSampleCount);
+  check(cc_eval_calc_batch(h, featureIdx, featureIdx + 1, nullptr, maxSampleCount, c.row.data(), 0), "CvFeatureEvaluator::operator()");
+  c.row_fi = featureIdx;
+  return c.row[(size_t)sampleIdx];
 }
 
 cv::Ptr<CvFeatureEvaluator> CvFeatureEvaluator::create(int type) {  // features.cpp:91-97

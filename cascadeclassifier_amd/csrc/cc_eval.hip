@@ -443,6 +443,36 @@ __global__ __launch_bounds__(64) void k_predict(PredictArgs A) {
   A.out[s] = pass;
 }
 
+// operator()(feature_idx[k], si) for a list of catalog features and one stored sample: one thread per list entry, the
+// sample's integral row read straight from global memory (2.5 KB, cache resident after the first touch).
+template <bool HAAR>
+__global__ __launch_bounds__(256) void k_eval_list(const void* __restrict__ feats, const int32_t* __restrict__ list, int n,
+                                                   const int32_t* __restrict__ sum_row, const int32_t* __restrict__ tilted_row,
+                                                   const float* __restrict__ nf_of_sample, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (HAAR) {
+    const float nf = *nf_of_sample;
+    const HaarFeatDev F = reinterpret_cast<const HaarFeatDev*>(feats)[list[i]];
+    const int32_t* b = F.tilted ? tilted_row : sum_row;
+    float ret = F.w[0] * (float)(b[F.p[0][0]] - b[F.p[0][1]] - b[F.p[0][2]] + b[F.p[0][3]]) +
+                F.w[1] * (float)(b[F.p[1][0]] - b[F.p[1][1]] - b[F.p[1][2]] + b[F.p[1][3]]);
+    if (F.w[2] != 0.0f) ret += F.w[2] * (float)(b[F.p[2][0]] - b[F.p[2][1]] - b[F.p[2][2]] + b[F.p[2][3]]);
+    out[i] = nf == 0.0f ? 0.0f : ret / nf;  // haarfeatures.h:108-112
+  } else {
+    const LbpFeatDev F = reinterpret_cast<const LbpFeatDev*>(feats)[list[i]];
+    int p[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) p[j] = sum_row[F.p[j]];
+    const int c = p[5] - p[6] - p[9] + p[10];
+    const int code = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
+                     (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
+                     (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
+                     (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
+    out[i] = (float)code;
+  }
+}
+
 // Feature::calc on caller-held integral rows: one thread per (feature, row).
 __global__ void k_feature_calc_rows(const HaarFeatDev* __restrict__ feats, int n_feats, const int32_t* __restrict__ sum,
                                     const int32_t* __restrict__ tilted, int n_rows, int row_len, float* __restrict__ out) {
@@ -818,6 +848,47 @@ cc_status cc_eval_calc(cc_evaluator* e, int fi, int si, float* out) {
   if (si < 0 || si >= e->max_samples) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc: sample %d out of range (%d)", si, e->max_samples);
   const int32_t idx = si;
   return cc_eval_calc_batch(e, fi, fi + 1, &idx, 1, out, 0);
+}
+
+cc_status cc_eval_calc_list(cc_evaluator* e, const int32_t* feature_idx, int n_feats, int si, float* out) {
+  if (!e || (n_feats > 0 && (!feature_idx || !out))) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_list: null argument");
+  if (n_feats < 0) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_list: negative count");
+  if (si < 0 || si >= e->max_samples) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc_list: sample %d out of range (%d)", si, e->max_samples);
+  for (int i = 0; i < n_feats; i++)
+    if (feature_idx[i] < 0 || feature_idx[i] >= e->nfeat)
+      return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc_list: feature %d out of range (%d)", feature_idx[i], e->nfeat);
+  cc_status st = eval_device(e);
+  if (st != CC_OK) return st;
+  if (n_feats == 0) return CC_OK;
+  const bool haar = e->type == CC_FEATURE_HAAR;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (haar && !e->d_haar_plain.p) {  // catalog with plain row offsets (row stride W + 1), built once
+    std::vector<HaarFeatDev> dev(e->haar.size());
+    for (size_t i = 0; i < dev.size(); i++) haar_to_dev(e->haar[i], e->W + 1, dev[i]);
+    CC_HIP(e->d_haar_plain.ensure(std::max<size_t>(dev.size(), 1)));
+    CC_HIP(hipMemcpy(e->d_haar_plain.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice));
+  }
+  if (!haar && !e->d_lbp_plain.p) {
+    std::vector<LbpFeatDev> dev((size_t)e->nfeat);
+    for (int i = 0; i < e->nfeat; i++) lbp_to_dev(&e->lbp[(size_t)i * 4], e->W + 1, dev[i]);
+    CC_HIP(e->d_lbp_plain.ensure(std::max<size_t>(dev.size(), 1)));
+    CC_HIP(hipMemcpy(e->d_lbp_plain.p, dev.data(), dev.size() * sizeof(LbpFeatDev), hipMemcpyHostToDevice));
+  }
+  CC_HIP(e->d_idx.ensure((size_t)n_feats));
+  CC_HIP(e->d_out.ensure((size_t)n_feats));
+  CC_HIP(hipMemcpyAsync(e->d_idx.p, feature_idx, (size_t)n_feats * 4, hipMemcpyHostToDevice, e->stream));
+  const int32_t* row = e->d_sum.p + (size_t)si * e->cols;
+  const int32_t* trow = e->use_tilted ? e->d_tilted.p + (size_t)si * e->cols : row;
+  if (haar)
+    hipLaunchKernelGGL(k_eval_list<true>, dim3((n_feats + 255) / 256), dim3(256), 0, e->stream, (const void*)e->d_haar_plain.p, e->d_idx.p,
+                       n_feats, row, trow, e->d_nf.p + si, e->d_out.p);
+  else
+    hipLaunchKernelGGL(k_eval_list<false>, dim3((n_feats + 255) / 256), dim3(256), 0, e->stream, (const void*)e->d_lbp_plain.p, e->d_idx.p,
+                       n_feats, row, trow, e->d_nf.p + si, e->d_out.p);
+  CC_HIP(hipGetLastError());
+  CC_HIP(hipMemcpyAsync(out, e->d_out.p, (size_t)n_feats * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  CC_HIP(hipStreamSynchronize(e->stream));
+  return CC_OK;
 }
 
 cc_status cc_eval_calc_custom_haar(cc_evaluator* e, const cc_haar_feature* feats, int n_feats, int normalized,

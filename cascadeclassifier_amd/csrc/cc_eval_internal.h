@@ -93,6 +93,8 @@ struct cc_evaluator {
   EBuf<int32_t> d_idx;
   EBuf<float> d_out;
   EBuf<HaarFeatDev> d_custom;
+  EBuf<HaarFeatDev> d_haar_plain;  // catalog with plain fastRect offsets (cc_eval_calc_list), built on first use
+  EBuf<LbpFeatDev> d_lbp_plain;
   EBuf<uint8_t> d_pred;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   double last_ms = 0;

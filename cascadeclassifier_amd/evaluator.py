@@ -74,6 +74,13 @@ class CvFeatureEvaluator:
         L.check(L.lib().cc_eval_calc(self._e, int(featureIdx), int(sampleIdx), C.byref(out)))
         return out.value
 
+    def calc_list(self, feature_idx, sample_idx: int) -> np.ndarray:
+        """operator()(fi, sample_idx) for an arbitrary list of features and one stored sample, one launch (cc_eval_calc_list)."""
+        fi = np.ascontiguousarray(feature_idx, np.int32)
+        out = np.empty(len(fi), np.float32)
+        L.check(L.lib().cc_eval_calc_list(self._e, _vp(fi), len(fi), int(sample_idx), _vp(out)))
+        return out
+
     def calc_batch(self, fi_begin, fi_end, sample_idx=None, n_samples=None) -> np.ndarray:
         idx = None if sample_idx is None else np.ascontiguousarray(sample_idx, np.int32)
         ns = len(idx) if idx is not None else (self.maxSampleCount if n_samples is None else n_samples)

@@ -271,8 +271,13 @@ CC_API cc_status cc_eval_set_image(cc_evaluator* e, const uint8_t* img, size_t r
 CC_API cc_status cc_eval_set_images(cc_evaluator* e, const uint8_t* imgs, int n, int first_idx, const uint8_t* labels);
 /* Host array of max_samples floats (the reference's `cls` Mat; o_cvcascadeboosttraindata.cpp:238-239 wraps it). */
 CC_API const float* cc_eval_labels(const cc_evaluator* e);
-/* Scalar operator()(featureIdx, sampleIdx): one device evaluation (slow; prefer the batch form). */
+/* Scalar operator()(featureIdx, sampleIdx): one device evaluation (slow; prefer the batch / list forms). */
 CC_API cc_status cc_eval_calc(cc_evaluator* e, int fi, int si, float* out);
+/* out[k] = evaluator(feature_idx[k], si) for an arbitrary list of features and ONE stored sample, in one launch: the call
+ * shape of the trainer's stage prediction on a freshly set window (CvCascadeBoostTree::predict ->
+ * CvCascadeBoostTrainData::getVarValue, o_cvcascadeboosttree.cpp:16-39, o_cvcascadeboosttraindata.cpp:484-488), which asks
+ * for the cascade's features one by one. The C++ adaptor batches those scalar calls through this entry point. */
+CC_API cc_status cc_eval_calc_list(cc_evaluator* e, const int32_t* feature_idx, int n_feats, int si, float* out);
 /* out[(fi - fi_begin) * n_samples + s] = evaluator(fi, sample_idx ? sample_idx[s] : s); out is HOST memory unless
  * out_on_device != 0 (then it is memory of the evaluator's device). */
 CC_API cc_status cc_eval_calc_batch(cc_evaluator* e, int fi_begin, int fi_end, const int32_t* sample_idx, int n_samples,

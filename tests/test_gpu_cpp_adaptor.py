@@ -52,3 +52,18 @@ def test_cpp_detection_tool_matches_python_path(haar_xml, tmp_path):
     got = np.array([[int(v) for v in line.split()] for line in r.stdout.strip().splitlines()], np.int32).reshape(-1, 4)
     assert got.shape == want.shape and (got == want).all() and len(got) >= 3
     assert subprocess.run([os.path.join(LIB, "detect_pgm"), "/nonexistent.xml", pgm], capture_output=True).returncode == 1
+
+
+@pytest.mark.gpu
+def test_unedited_trainer_loop_matches_batched_mining(haar_xml, tmp_path):
+    """examples/bench_unedited_trainer.cpp: the reference's window-by-window negative-mining loop (setImage + one
+    operator() per weak classifier) through the adaptor's queued setImage / learned-list cache gives every window the
+    verdict of cc_negminer_run on the same stream (10 trained stages of the synthetic cascade, 640x480 background)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    trunc = os.path.join(str(tmp_path), "trunc10.xml")
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "truncate_cascade.py"), haar_xml, "10", trunc])
+    r = subprocess.run([os.path.join(LIB, "bench_unedited_trainer"), trunc], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-2000:], r.stderr[-1000:])
+    assert r.returncode == 0
+    assert "verdicts identical to the batched path: yes" in r.stdout

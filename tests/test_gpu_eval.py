@@ -302,3 +302,31 @@ def test_hoisted_division_is_the_division_operator():
     bad = C.c_uint64(123)
     L.check(L.lib().cc_debug_division_check(0, 1 << 32, 20261004, C.byref(bad)))
     assert bad.value == 0
+
+
+@pytest.mark.parametrize("ftype,mode", [(ev.HAAR, ev.ALL), (ev.LBP, 0)])
+def test_feature_list_of_one_sample_matches_the_bulk_values(ftype, mode):
+    """cc_eval_calc_list (the shape of the trainer's stage prediction on one freshly set window): any list of catalog
+    features, repeated and unordered, for one stored sample == the same entries of the bulk evaluation == the oracle."""
+    rng = np.random.default_rng(5)
+    imgs = rng.integers(0, 256, (6, 24, 24), dtype=np.uint8)
+    imgs[4] = 200  # flat sample: norm factor 0 -> Haar values 0
+    e = cc.CvFeatureEvaluator.create(ftype)
+    e.init(cc.CvFeatureParams(ftype, mode), 6, (24, 24))
+    e.setImages(imgs)
+    F = e.getNumFeatures()
+    lst = np.concatenate([rng.integers(0, F, 3000), [0, F - 1, 7, 7, 7]]).astype(np.int32)
+    if ftype == ev.HAAR:
+        s, t, nf = orc.set_images(imgs, want_tilted=True)
+        want_all = orc.haar_eval_batch(orc.haar_catalog(24, 24, mode), 0, F, s, t, nf, 24, 24)
+    else:
+        s, t, nf = orc.set_images(imgs, want_norm=False)
+        want_all = orc.lbp_eval_batch(orc.lbp_catalog(24, 24), 0, F, s, 24, 24)
+    for si in (0, 3, 4, 5):
+        got = e.calc_list(lst, si)
+        assert (got.view(np.uint32) == want_all[lst, si].view(np.uint32)).all()
+    assert len(e.calc_list([], 2)) == 0
+    with pytest.raises(cc.CascadeError):
+        e.calc_list([F], 0)
+    with pytest.raises(cc.CascadeError):
+        e.calc_list([0], 6)
