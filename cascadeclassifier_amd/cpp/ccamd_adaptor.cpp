@@ -1,5 +1,7 @@
 // Implementation of the C++ host adaptor (see ccamd/traincascade_features.hpp). Everything numeric is delegated to the
 // C ABI (HIP kernels); status codes become cv::Exception like the reference's CV_Assert / CV_Error failures.
+#include <locale.h>
+
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +11,18 @@
 #include "ccamd/traincascade_features.hpp"
 
 namespace {
+
+// printf("%e") / strtod follow the calling thread's LC_NUMERIC; XML numbers must not (same guard as the library's).
+struct CNumericLocale {
+  locale_t prev = (locale_t)0;
+  CNumericLocale() {
+    static locale_t c = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+    if (c != (locale_t)0) prev = uselocale(c);
+  }
+  ~CNumericLocale() {
+    if (prev != (locale_t)0) uselocale(prev);
+  }
+};
 
 [[noreturn]] void throw_last(const char* where) {
   throw cv::Exception(-1, std::string(where) + ": " + cc_last_error());
@@ -134,6 +148,7 @@ bool FileNode::isReal() const {
   const std::string t = text();
   if (t.empty()) return false;
   char* end = nullptr;
+  const CNumericLocale c_numbers;
   (void)std::strtod(t.c_str(), &end);
   return end && *end == 0;
 }
@@ -146,7 +161,10 @@ FileNode FileNode::operator[](const std::string& key) const {
 FileNode::operator int() const {  // like OpenCV: a missing node reads as 0
   return e_ ? (int)std::strtol(text().c_str(), nullptr, 10) : 0;
 }
-FileNode::operator double() const { return e_ ? std::strtod(text().c_str(), nullptr) : 0.0; }
+FileNode::operator double() const {
+  const CNumericLocale c_numbers;
+  return e_ ? std::strtod(text().c_str(), nullptr) : 0.0;
+}
 
 bool FileStorage::open(const std::string& filename, int flags) {
   release();
@@ -278,6 +296,7 @@ FileStorage& operator<<(FileStorage& fs, const char* s) { return fs.put(std::str
 FileStorage& operator<<(FileStorage& fs, int v) { return fs.putNumber(std::to_string(v)); }
 FileStorage& operator<<(FileStorage& fs, bool v) { return fs.putNumber(v ? "1" : "0"); }
 static std::string real_text(double v, const char* fmt) {
+  const CNumericLocale c_numbers;
   if (v == (double)(long long)v && v > -1e15 && v < 1e15) {  // OpenCV prints integral reals as "2."
     char b[64];
     snprintf(b, sizeof(b), "%lld.", (long long)v);

@@ -303,6 +303,7 @@ cc_status write_text_file(const char* path, const std::string& text) {
 extern "C" {
 
 cc_status cc_cascade_load_xml_mem(const char* text, size_t len, cc_cascade** out) {
+  const CNumericLocale c_numbers;  // "%.8e" / strtod must not follow the host program's LC_NUMERIC
   if (!text || !out) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_load_xml_mem: null argument");
   *out = nullptr;
   XmlNode root;
@@ -332,6 +333,7 @@ cc_status cc_cascade_load_xml(const char* path, cc_cascade** out) {
 void cc_cascade_destroy(cc_cascade* c) { delete c; }
 
 cc_status cc_cascade_save_xml(const cc_cascade* c, const char* path) {
+  const CNumericLocale c_numbers;  // "%.8e" / strtod must not follow the host program's LC_NUMERIC
   if (!c || !path) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_save_xml: null argument");
   const Cascade& m = c->m;
   const bool haar = m.feature_type == CC_FEATURE_HAAR;
@@ -391,6 +393,7 @@ cc_status cc_cascade_save_xml(const cc_cascade* c, const char* path) {
 }
 
 cc_status cc_cascade_save_xml_legacy(const cc_cascade* c, const char* path) {
+  const CNumericLocale c_numbers;  // "%.8e" / strtod must not follow the host program's LC_NUMERIC
   if (!c || !path) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_save_xml_legacy: null argument");
   const Cascade& m = c->m;
   if (m.feature_type != CC_FEATURE_HAAR)

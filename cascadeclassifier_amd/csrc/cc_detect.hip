@@ -915,6 +915,7 @@ template <int STEP>
 static void build_lbp_stumps(const Cascade& m, std::vector<LbpStumpDev>& out);
 
 static std::string spec_stage_source(const Cascade& m, int n_stages) {
+  const CNumericLocale c_numbers;  // "%a" literals must not follow the host program's LC_NUMERIC
   if (m.feature_type == CC_FEATURE_LBP) return spec_stage_source_lbp(m, n_stages);
   std::vector<HaarStumpDev> t[2];
   build_haar_stumps<1>(m, t[0]);
@@ -1839,6 +1840,7 @@ struct HipRtcApi {
   int (*code_size)(void*, size_t*) = nullptr;
   int (*code)(void*, char*) = nullptr;
   int (*destroy)(void**) = nullptr;
+  int (*version)(int*, int*) = nullptr;  // optional
   bool ok() const { return create && compile && log_size && log && code_size && code && destroy; }
 };
 
@@ -1859,6 +1861,7 @@ static const HipRtcApi& hiprtc_api() {
     api.code_size = reinterpret_cast<decltype(api.code_size)>(sym("hiprtcGetCodeSize"));
     api.code = reinterpret_cast<decltype(api.code)>(sym("hiprtcGetCode"));
     api.destroy = reinterpret_cast<decltype(api.destroy)>(sym("hiprtcDestroyProgram"));
+    api.version = reinterpret_cast<decltype(api.version)>(sym("hiprtcVersion"));
   });
   return api;
 }
@@ -1880,7 +1883,13 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
   const std::string o_w0 = "-DCC_SPEC_W0=" + std::to_string(win_w), o_h0 = "-DCC_SPEC_H0=" + std::to_string(win_h);  // tile geometry folds to constants
   const char* opts[] = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str(), o_w.c_str(), o_w0.c_str(), o_h0.c_str(), "-DCC_SPEC_LBP"};
   const int n_opts = (int)(sizeof(opts) / sizeof(opts[0])) - (lbp ? 0 : 1);
-  std::string key;  // everything the code object depends on: options, then the source
+  std::string key;  // everything the code object depends on: compiler version, options, then the source
+  {
+    int major = 0, minor = 0;
+    const HipRtcApi& rtc = hiprtc_api();
+    if (rtc.version) (void)rtc.version(&major, &minor);
+    key += "hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " ";
+  }
   for (int i = 0; i < n_opts; i++) key += std::string(opts[i]) + " ";
   key += "#" + src;
   {
@@ -1891,8 +1900,25 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
       return CC_OK;
     }
   }
-  // second level: code objects on disk ($CCAMD_CACHE_DIR, else ~/.cache/cascadeclassifier_amd; CCAMD_CACHE_DIR= disables),
-  // named by a 64-bit FNV-1a hash of architecture, options and source; the file repeats the key length as a check
+  // second level: code objects on disk ($CCAMD_CACHE_DIR, else ~/.cache/cascadeclassifier_amd; CCAMD_CACHE_DIR= disables).
+  // The file is named by a 64-bit FNV-1a hash of the key and starts with a header that repeats the key's length and two
+  // independent 64-bit hashes of it; the key covers architecture, options, the hiprtc version and the generated source.
+  // A file whose header does not match (another toolchain, a collision, a foreign or truncated file) is ignored and
+  // rewritten: a wrong code object would carry another cascade's thresholds and give wrong detections silently.
+  struct CacheHeader {
+    char magic[8];
+    unsigned long long key_len, h1, h2;
+  };
+  auto hash_key = [&](unsigned long long seed, unsigned long long prime) {
+    unsigned long long h = seed;
+    for (unsigned char ch : key) h = (h ^ ch) * prime;
+    return h ^ (h >> 29);
+  };
+  CacheHeader want;
+  std::memcpy(want.magic, "CCAMDSP2", 8);
+  want.key_len = key.size();
+  want.h1 = hash_key(1469598103934665603ull, 1099511628211ull);
+  want.h2 = hash_key(0x9E3779B97F4A7C15ull, 0x100000001B3ull * 31ull + 2ull);
   std::string cache_file;
   {
     const char* dir = std::getenv("CCAMD_CACHE_DIR");
@@ -1902,17 +1928,20 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
     else if (const char* home = std::getenv("HOME"))
       base = std::string(home) + "/.cache/cascadeclassifier_amd";
     if (!base.empty()) {
-      unsigned long long h = 1469598103934665603ull;
-      for (unsigned char ch : key) h = (h ^ ch) * 1099511628211ull;
       char name[64];
-      snprintf(name, sizeof(name), "/spec_%016llx_%zu.hsaco", h, key.size());
+      snprintf(name, sizeof(name), "/spec_%016llx_%zu.hsaco", want.h1, key.size());
       cache_file = base + name;
       if (FILE* f = std::fopen(cache_file.c_str(), "rb")) {
         std::fseek(f, 0, SEEK_END);
         const long n = std::ftell(f);
         std::fseek(f, 0, SEEK_SET);
-        std::vector<char> buf(n > 0 ? (size_t)n : 0);
-        const bool ok = n > 64 && std::fread(buf.data(), 1, buf.size(), f) == buf.size() && std::memcmp(buf.data(), "\x7f" "ELF", 4) == 0;
+        CacheHeader got;
+        std::vector<char> buf;
+        bool ok = n > (long)sizeof(CacheHeader) + 64 && std::fread(&got, sizeof(got), 1, f) == 1 && std::memcmp(&got, &want, sizeof(want)) == 0;
+        if (ok) {
+          buf.resize((size_t)n - sizeof(CacheHeader));
+          ok = std::fread(buf.data(), 1, buf.size(), f) == buf.size() && std::memcmp(buf.data(), "\x7f" "ELF", 4) == 0;
+        }
         std::fclose(f);
         if (ok) {
           code = buf;
@@ -1964,7 +1993,7 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
   if (!cache_file.empty()) {  // write to a private name, then rename: readers never see a partial file
     const std::string tmp = cache_file + "." + std::to_string((long long)::getpid()) + ".tmp";
     if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
-      const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
+      const bool ok = std::fwrite(&want, sizeof(want), 1, f) == 1 && std::fwrite(code.data(), 1, code.size(), f) == code.size();
       std::fclose(f);
       if (!ok || std::rename(tmp.c_str(), cache_file.c_str()) != 0) (void)std::remove(tmp.c_str());
     }

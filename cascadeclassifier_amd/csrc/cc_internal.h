@@ -9,7 +9,26 @@
 
 #include "../../include/cascadeclassifier_amd.h"
 
+#include <locale.h>
+
 namespace ccamd {
+
+// Numbers in cascade XML and in generated kernel source are written and parsed with printf / strtod, which follow the
+// calling thread's LC_NUMERIC: under a comma-decimal locale (a host program that called setlocale(LC_ALL, "")) "%.8e"
+// would print "1,5e+00" and strtod would stop at the '.' of "1.5". Entry points that format or parse numbers hold one
+// of these: it switches the calling THREAD to the "C" locale for its lifetime (uselocale; no other thread is affected).
+struct CNumericLocale {
+  locale_t prev = (locale_t)0;
+  CNumericLocale() {
+    static locale_t c = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+    if (c != (locale_t)0) prev = uselocale(c);
+  }
+  ~CNumericLocale() {
+    if (prev != (locale_t)0) uselocale(prev);
+  }
+  CNumericLocale(const CNumericLocale&) = delete;
+  CNumericLocale& operator=(const CNumericLocale&) = delete;
+};
 
 // ---- error plumbing (thread-local message behind cc_last_error) -------------------------------
 cc_status set_error(cc_status code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));

@@ -162,3 +162,41 @@ def test_legacy_base_format_writer(tmp_path, haar_xml, which):
 def test_legacy_base_format_is_haar_only(tmp_path, lbp_xml):
     with pytest.raises(cc.CascadeError, match="old file format is used for Haar-like features only"):
         cc.CascadeClassifier(lbp_xml).save(os.path.join(str(tmp_path), "x.xml"), baseFormat=True)
+
+
+def test_numbers_do_not_follow_the_host_programs_locale(tmp_path):
+    """A host program that called setlocale(LC_ALL, "") under a comma-decimal locale must still get cascade XML with '.'
+    decimals and must still parse it (and generated kernel source with valid float literals). Needs such a locale on
+    the machine; skipped where none is installed."""
+    import locale
+    import ctypes as C
+
+    from cascadeclassifier_amd import _lib as L
+    old = locale.setlocale(locale.LC_NUMERIC)
+    chosen = None
+    for name in ("de_DE.UTF-8", "de_DE.utf8", "fr_FR.UTF-8", "fr_FR.utf8", "ru_RU.UTF-8", "nl_NL.UTF-8"):
+        try:
+            locale.setlocale(locale.LC_NUMERIC, name)
+            chosen = name
+            break
+        except locale.Error:
+            continue
+    if chosen is None:
+        pytest.skip("no comma-decimal locale installed")
+    try:
+        assert locale.localeconv()["decimal_point"] == ","
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        src = os.path.join(root, "data", "haarcascade_frontalface_synthetic.xml")
+        c = C.c_void_p()
+        L.check(L.lib().cc_cascade_load_xml(src.encode(), C.byref(c)))
+        out = os.path.join(str(tmp_path), "again.xml")
+        L.check(L.lib().cc_cascade_save_xml(c, out.encode()))
+        text = open(out).read()
+        assert "," not in text.split("<stages>")[1].split("</stages>")[0]
+        c2 = C.c_void_p()
+        L.check(L.lib().cc_cascade_load_xml(out.encode(), C.byref(c2)))
+        n = C.c_size_t(0)
+        L.check(L.lib().cc_cascade_compile_specialized(c2, 2, b"gfx950", C.byref(n)))  # "%a" literals compile
+        assert n.value > 0
+    finally:
+        locale.setlocale(locale.LC_NUMERIC, old)

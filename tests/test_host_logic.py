@@ -186,3 +186,44 @@ def test_specialised_kernel_source_compiles_for_gfx950(haar_xml):
     L.check(lib.cc_cascade_compile_specialized(c, 2, b"gfx950", C.byref(m)))
     assert m.value == n.value and time.perf_counter() - t0 < 0.5
     lib.cc_cascade_destroy(c)
+
+
+def test_disk_cache_of_specialised_code_checks_its_header(haar_xml, tmp_path):
+    """A cached code object is only loaded if its header repeats the key's length and hashes (the key covers hiprtc
+    version, options and source): a file for another key -- simulated by damaging the header -- is ignored, the kernel is
+    recompiled and the file rewritten. Each step in its own process (the in-process cache would hide the file)."""
+    import glob
+    import subprocess
+    import sys
+    cache = str(tmp_path)
+    code = ("import ctypes as C, sys, time; sys.path.insert(0, %r); from cascadeclassifier_amd import _lib as L; lib = L.lib(); c = C.c_void_p(); "
+            "L.check(lib.cc_cascade_load_xml(%r.encode(), C.byref(c))); n = C.c_size_t(0); t = time.perf_counter(); "
+            "st = lib.cc_cascade_compile_specialized(c, 2, b'gfx950', C.byref(n)); print(st, n.value, time.perf_counter() - t, lib.cc_last_error().decode())"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), haar_xml))
+    env = dict(os.environ, CCAMD_CACHE_DIR=cache)
+
+    def run():
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        st, size, secs = r.stdout.split()[:3]
+        return int(st), int(size), float(secs), r.stdout
+
+    st, size, t_first, out = run()
+    if st != 0 and "libhiprtc" in out:
+        pytest.skip(out)
+    assert st == 0
+    files = glob.glob(os.path.join(cache, "spec_*.hsaco"))
+    assert len(files) == 1
+    blob = open(files[0], "rb").read()
+    assert blob[:8] == b"CCAMDSP2" and blob[32:36] == b"\x7fELF" and len(blob) == size + 32
+    st, size2, t_cached, _ = run()
+    assert st == 0 and size2 == size and t_cached < t_first * 0.5  # served from disk
+    damaged = bytearray(blob)
+    damaged[24] ^= 0x5A  # second hash of the key: as if the file belonged to another source
+    open(files[0], "wb").write(bytes(damaged))
+    st, size3, t_again, _ = run()
+    assert st == 0 and size3 == size and t_again > t_cached * 2  # ignored: compiled again ...
+    assert open(files[0], "rb").read() == blob                   # ... and written back with a matching header
+    open(files[0], "wb").write(blob[:40])  # truncated file: ignored as well
+    st, size4, _, _ = run()
+    assert st == 0 and size4 == size and open(files[0], "rb").read() == blob
