@@ -797,7 +797,7 @@ static cc_status ensure_device(int device) {
 // integer multiples of q = 2^(emin-23) (emin = smallest exponent among the stage's nonzero leaves) and the sum of the
 // larger leaf magnitudes divided by q stays below 2^53. Then the double accumulation never rounds, so its result
 // does not depend on the order of the additions.
-static bool stage_sums_order_independent(const Cascade& m) {
+static bool stage_sums_order_independent(const Cascade& m, double headroom = 1.0) {
   for (size_t s = 0; s < m.stage_ntrees.size(); s++) {
     int emin = INT32_MAX;
     double mag = 0;
@@ -816,7 +816,7 @@ static bool stage_sums_order_independent(const Cascade& m) {
     if (emin == INT32_MAX) continue;
     // v = f * 2^e with f in [0.5, 1) and a 24-bit significand: v is a multiple of 2^(e-24); subnormals only get coarser
     const double q = std::ldexp(1.0, emin - 24);
-    if (mag / q >= 9007199254740992.0) return false;
+    if (mag * headroom / q >= 9007199254740992.0) return false;
   }
   return true;
 }
@@ -871,6 +871,7 @@ struct SpecStump {
   std::string loads;    // statements "x = b[..];" (variables are declared by the caller)
   std::string decls;    // declarations of those variables
   std::string compute;  // statement adding the stump's vote to `acc`
+  double base = 0.;     // constant part of the vote, added once per part (delta form, see spec_stage_source)
 };
 
 static int spec_prefetch_depth() {
@@ -880,7 +881,7 @@ static int spec_prefetch_depth() {
 }
 
 // Emits the body of one stage from per-stump pieces (see above). `suffixes` = one accumulator / window per entry.
-static void spec_emit_stage(std::string& o, const std::vector<SpecStump>& st, int depth, bool parts) {
+static void spec_emit_stage(std::string& o, const std::vector<SpecStump>& st, int depth, bool parts, const std::vector<std::string>& accs) {
   const int nt = (int)st.size();
   static const char* kSB = "      __builtin_amdgcn_sched_barrier(0);\n";
   for (const SpecStump& t : st) o += "      " + t.decls + "\n";
@@ -901,6 +902,15 @@ static void spec_emit_stage(std::string& o, const std::vector<SpecStump>& st, in
       o += buf;
     } else
       o += "      {\n";
+    {  // constant parts of this part's votes (delta form): one exact addition per accumulator
+      double base = 0.;
+      for (int i = e0; i < e1; i++) base += st[(size_t)i].base;
+      if (base != 0.) {
+        char lit[64];
+        snprintf(lit, sizeof(lit), "%a", base);
+        for (const std::string& a : accs) o += "      " + a + " += " + lit + ";\n";
+      }
+    }
     for (int i = e0; i < e1; i++) {
       if (depth > 0 && i + depth < nt) o += "      " + st[(size_t)(i + depth)].loads + "\n" + kSB;
       if (depth == 0) o += "      " + st[(size_t)i].loads + "\n";
@@ -922,6 +932,12 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
   build_haar_stumps<2>(m, t[1]);
   n_stages = std::min<int>(n_stages, (int)m.stage_ntrees.size());
   const int depth = spec_prefetch_depth();
+  // Delta form of a vote: `(v < thr ? left : right)` needs both leaf values in registers (a select takes one literal), and
+  // the compiler hoists those ~2 registers per stump out of the stage loop until it spills; `right + (v < thr ? left - right
+  // : 0)` selects between ONE literal and zero, and the `right`s of a part add up to one constant. Exact -- hence equal to
+  // the sequential sum of the votes -- when every partial sum of leaves and differences is representable
+  // (stage_sums_order_independent with headroom for the differences); otherwise the plain form is generated.
+  const bool delta_form = stage_sums_order_independent(m, 4.0) && !std::getenv("CCAMD_SPEC_NO_DELTA");
   std::string o;
   char buf[512];
   auto hexf = [&](float v) {
@@ -987,7 +1003,45 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
     }
     if (out.decls.empty()) out.decls = "";
     else out.decls += ";";
-    out.compute = e + "; v *= vnf" + win + "; acc" + win + " += (double)(v < " + hexf(d.thr) + " ? " + hexf(d.left) + " : " + hexf(d.right) + "); }";
+    if (const char* dbg = std::getenv("CCAMD_DEBUG_SPEC_MODE")) {
+      // Sensitivity experiments (tools/sweeps): extra work whose results are thrown away, decisions unchanged.
+      // 3 = every LDS read issued twice; 4 = the value arithmetic done twice. Measured on the headline bench:
+      // mode 3 costs +68 % kernel time, mode 4 +1 %: the kernel is bound by the LDS pipeline, not by VALU issue.
+      const int mode = std::atoi(dbg);
+      if (mode == 3) {
+        std::string dup;
+        int k = 0;
+        for (auto& kv : var) {
+          snprintf(buf, sizeof(buf), "{ unsigned dz%d = (unsigned)b%s[%d]; asm volatile(\"\" :: \"v\"(dz%d)); } ", k, win.c_str(), kv.first ^ 1, k);
+          dup += buf;
+          k++;
+        }
+        out.compute = dup + " ";
+      } else if (mode == 4) {
+        std::string e2 = e;  // same operations on other operand values, so that they cannot be merged with the real ones
+        for (auto& kv : var) {
+          size_t pos = 0;
+          const std::string from = kv.second, to = "(" + kv.second + " + 77u)";
+          while ((pos = e2.find(from, pos)) != std::string::npos) {
+            const char next = pos + from.size() < e2.size() ? e2[pos + from.size()] : ' ';
+            if (next >= '0' && next <= '9') {
+              pos += from.size();
+              continue;
+            }
+            e2.replace(pos, from.size(), to);
+            pos += to.size();
+          }
+        }
+        out.compute = e2 + "; v *= vnf" + win + "; asm volatile(\"\" :: \"v\"(v)); } ";
+      }
+    }
+    if (delta_form) {  // vote = right + (v < thr ? left - right : 0): the constant `right` is added once per part
+      char delta[64];  // (hexf reuses `buf`)
+      snprintf(delta, sizeof(delta), "%a", (double)d.left - (double)d.right);
+      out.compute += e + "; v *= vnf" + win + "; acc" + win + " += (v < " + hexf(d.thr) + " ? " + delta + " : 0.); }";
+      out.base = (double)d.right;
+    } else
+      out.compute += e + "; v *= vnf" + win + "; acc" + win + " += (double)(v < " + hexf(d.thr) + " ? " + hexf(d.left) + " : " + hexf(d.right) + "); }";
     return out;
   };
   for (int step = 1; step <= 2; step++) {
@@ -1001,7 +1055,7 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
       std::vector<SpecStump> st;
       for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++)
         st.push_back(stump(t[step - 1][(size_t)m.stage_first[(size_t)s] + i], m.stage_first[(size_t)s] + i, i, ""));
-      spec_emit_stage(o, st, depth, true);
+      spec_emit_stage(o, st, depth, true, {"acc"});
       o += "    } break;\n";
     }
     o += "    default: break;\n  }\n  return acc;\n}\n";
@@ -1016,9 +1070,9 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
       for (int i = 0; i < m.stage_ntrees[0]; i++) {
         const HaarStumpDev& d = t[step - 1][(size_t)m.stage_first[0] + i];
         SpecStump a = stump(d, m.stage_first[0] + i, i, "a"), b2 = stump(d, m.stage_first[0] + i, i, "b");
-        st.push_back(SpecStump{a.loads + b2.loads, a.decls + " " + b2.decls, a.compute + " " + b2.compute});
+        st.push_back(SpecStump{a.loads + b2.loads, a.decls + " " + b2.decls, a.compute + " " + b2.compute, a.base});
       }
-      spec_emit_stage(o, st, depth, false);
+      spec_emit_stage(o, st, depth, false, {"acca", "accb"});
     }
     o += "  }\n  acc_a = acca;\n  acc_b = accb;\n}\n";
   }
@@ -1084,7 +1138,7 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages) {
         const int idx = m.stage_first[(size_t)s] + i;
         st.push_back(stump(t[step - 1][(size_t)idx], idx, i, ""));
       }
-      spec_emit_stage(o, st, depth, true);
+      spec_emit_stage(o, st, depth, true, {"acc"});
       o += "    } break;\n";
     }
     o += "    default: break;\n  }\n  return acc;\n}\n";
@@ -1100,7 +1154,7 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages) {
         SpecStump a = stump(t[step - 1][(size_t)idx], idx, i, "a"), b2 = stump(t[step - 1][(size_t)idx], idx, i, "b");
         st.push_back(SpecStump{a.loads + b2.loads, a.decls + " " + b2.decls, a.compute + " " + b2.compute});
       }
-      spec_emit_stage(o, st, std::min(depth, 1), false);
+      spec_emit_stage(o, st, std::min(depth, 1), false, {"acca", "accb"});
     }
     o += "  }\n  acc_a = acca;\n  acc_b = accb;\n}\n";
   }
