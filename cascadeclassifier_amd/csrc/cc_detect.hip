@@ -2210,7 +2210,7 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
       CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(haar ? &k_eval_haar : &k_eval_lbp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds));
   }
   if (const char* e = std::getenv("CCAMD_WAVE_BELOW"))  // tuning knob; only honoured when the reduction is exact
-    if (d->wave_below) d->wave_below = std::max(0, std::atoi(e));
+    if (d->wave_below) d->wave_below = std::max(0, std::min(64, std::atoi(e)));  // the wave phase holds one window per lane
   CC_HIP(d->d_stage_thr.upload(d->m.stage_threshold, d->stream));
   if (trees) {
     std::vector<int> root(d->m.tree_first_node.begin(), d->m.tree_first_node.end()), leaf0(d->m.tree_first_leaf.begin(), d->m.tree_first_leaf.end());

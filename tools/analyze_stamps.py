@@ -13,6 +13,10 @@ total = end - st[:, 0]
 print("blocks", len(st), "mean block cycles", total.mean(), "median", np.median(total))
 prev = st[:, 0].copy()
 names = ["staging", "dense(var+s0)"] + ["stage %d" % k for k in range(1, slots - 3)]
+if slots == 40:  # wave-phase stamps: slot 30 = windows collected, 31 + i = i-th wave-phase stage done
+    names[29] = "W: collect"
+    for i in range(8):
+        names[30 + i] = "W: stage +%d" % i
 for k in range(1, slots - 1):
     cur = st[:, k]
     have = cur > 0
@@ -22,7 +26,7 @@ for k in range(1, slots - 1):
     print("%-14s reached by %5.1f%% of blocks  mean cycles (over all blocks) %8.0f  (over blocks that ran it) %8.0f" % (names[k - 1], 100 * have.mean(), d.mean(), d[have].mean()))
     prev = np.where(have, cur, prev)
 tail = end - prev
-print("%-14s mean cycles %8.0f" % ("wave phase", tail.mean()))
+print("%-14s mean cycles %8.0f" % ("rest (wave phase tail)", tail.mean()))
 k0 = st[:, 0].min()
 span = end.max() - k0
 print("kernel span cycles", span, "sum of block cycles / span =", total.sum() / span, "(average blocks in flight)")
