@@ -872,6 +872,7 @@ struct SpecStump {
   std::string decls;    // declarations of those variables
   std::string compute;  // statement adding the stump's vote to `acc`
   double base = 0.;     // constant part of the vote, added once per part (delta form, see spec_stage_source)
+  long long base_q = 0; // the same in units of the stage's quantum (fixed-point form)
 };
 
 static int spec_prefetch_depth() {
@@ -881,7 +882,8 @@ static int spec_prefetch_depth() {
 }
 
 // Emits the body of one stage from per-stump pieces (see above). `suffixes` = one accumulator / window per entry.
-static void spec_emit_stage(std::string& o, const std::vector<SpecStump>& st, int depth, bool parts, const std::vector<std::string>& accs) {
+static void spec_emit_stage(std::string& o, const std::vector<SpecStump>& st, int depth, bool parts, const std::vector<std::string>& accs,
+                            bool fixed_point = false) {
   const int nt = (int)st.size();
   static const char* kSB = "      __builtin_amdgcn_sched_barrier(0);\n";
   for (const SpecStump& t : st) o += "      " + t.decls + "\n";
@@ -904,12 +906,18 @@ static void spec_emit_stage(std::string& o, const std::vector<SpecStump>& st, in
       o += "      {\n";
     {  // constant parts of this part's votes (delta form): one exact addition per accumulator
       double base = 0.;
-      for (int i = e0; i < e1; i++) base += st[(size_t)i].base;
-      if (base != 0.) {
-        char lit[64];
-        snprintf(lit, sizeof(lit), "%a", base);
-        for (const std::string& a : accs) o += "      " + a + " += " + lit + ";\n";
+      unsigned base_q = 0;  // modulo 2^32, like the accumulator
+      for (int i = e0; i < e1; i++) {
+        base += st[(size_t)i].base;
+        base_q += (unsigned)st[(size_t)i].base_q;
       }
+      char lit[64];
+      if (fixed_point)
+        snprintf(lit, sizeof(lit), "%uu", base_q);
+      else
+        snprintf(lit, sizeof(lit), "%a", base);
+      if (fixed_point ? base_q != 0 : base != 0.)
+        for (const std::string& a : accs) o += "      " + a + " += " + lit + ";\n";
     }
     for (int i = e0; i < e1; i++) {
       if (depth > 0 && i + depth < nt) o += "      " + st[(size_t)(i + depth)].loads + "\n" + kSB;
@@ -938,6 +946,7 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
   // the sequential sum of the votes -- when every partial sum of leaves and differences is representable
   // (stage_sums_order_independent with headroom for the differences); otherwise the plain form is generated.
   const bool delta_form = stage_sums_order_independent(m, 4.0) && !std::getenv("CCAMD_SPEC_NO_DELTA");
+  const bool fixed_point_ok = !std::getenv("CCAMD_SPEC_NO_FIXED");  // tuning / bisecting
   std::string o;
   char buf[512];
   auto hexf = [&](float v) {
@@ -949,7 +958,30 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
   // equals (float) of the same combination computed in int32: corners shared by the rectangles merge, one conversion
   // instead of three, no float multiplies. Otherwise the float expression is emitted term by term.
   // `win` names the window (variables x<stump>_<k><win>, base pointer b<win>, vnf<win>, acc<win>).
-  auto stump = [&](const HaarStumpDev& d, int stump_index, int local, const std::string& win) {
+  // Fixed-point votes. Where a stage's leaves are all multiples of q = 2^k and the sum of their magnitudes stays below
+  // 2^31 q, the stage sum of ANY subset of votes is an int32 multiple of q: the delta-form votes are then accumulated as
+  // 32-bit integers (one select + one add per stump instead of two selects and a double add; intermediate wrap-around
+  // is harmless modulo 2^32) and converted once, exactly, at the end: (double)(int)acc * q is the same real number the
+  // double accumulation produces, so every comparison and reported sum is bit-identical.
+  auto stage_quantum = [&](int s, double& q) {
+    int emin = INT32_MAX;
+    double mag = 0;
+    for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++) {
+      const size_t k = (size_t)m.stage_first[(size_t)s] + i;
+      const float l = m.stump_left[k], r = m.stump_right[k];
+      mag += std::max(std::fabs((double)l), std::fabs((double)r));
+      for (float v : {l, r})
+        if (v != 0.0f) {
+          int e;
+          std::frexp(v, &e);
+          emin = std::min(emin, e);
+        }
+    }
+    if (emin == INT32_MAX) return false;
+    q = std::ldexp(1.0, emin - 24);  // every leaf is a multiple of q (see stage_sums_order_independent)
+    return mag / q < 2147483647.0;
+  };
+  auto stump = [&](const HaarStumpDev& d, int stump_index, int local, const std::string& win, double fixed_q) {
     const int fi = m.stump_feature[(size_t)stump_index];
     bool int_ok = true;
     double bound = 0;
@@ -1018,10 +1050,12 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
         }
         out.compute = dup + " ";
       } else if (mode == 4) {
-        std::string e2 = e;  // same operations on other operand values, so that they cannot be merged with the real ones
+        // the same operations on operands XOR-ed with a value the compiler cannot see through (an added constant would
+        // cancel in a - b - c + d and the copy would be merged with the original)
+        std::string e2 = e;
         for (auto& kv : var) {
           size_t pos = 0;
-          const std::string from = kv.second, to = "(" + kv.second + " + 77u)";
+          const std::string from = kv.second, to = "(" + kv.second + " ^ __float_as_uint(vnf" + win + "))";
           while ((pos = e2.find(from, pos)) != std::string::npos) {
             const char next = pos + from.size() < e2.size() ? e2[pos + from.size()] : ' ';
             if (next >= '0' && next <= '9') {
@@ -1035,7 +1069,21 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
         out.compute = e2 + "; v *= vnf" + win + "; asm volatile(\"\" :: \"v\"(v)); } ";
       }
     }
-    if (delta_form) {  // vote = right + (v < thr ? left - right : 0): the constant `right` is added once per part
+    if (delta_form && fixed_q > 0.) {
+      char delta[64];
+      const long long lq = (long long)std::llround((double)d.left / fixed_q), rq = (long long)std::llround((double)d.right / fixed_q);
+      // The delta reaches the select through a volatile move (left to itself the compiler hoists hundreds of these
+      // constant moves out of the stage loops and spills them), and the accumulator passes through an empty asm after
+      // every vote: integer adds are associative, and without it the compiler re-associates the chain of votes into a
+      // tree of partial sums that it then has to spill.
+      snprintf(delta, sizeof(delta), "0x%08x", (unsigned)(lq - rq));
+      char vote[256];
+      snprintf(vote, sizeof(vote), "; v *= vnf%s; { unsigned dq; asm volatile(\"v_mov_b32_e32 %%0, %s\" : \"=v\"(dq)); ai%s += (v < %s ? dq : 0u); asm volatile(\"\" : \"+v\"(ai%s)); } }",
+               win.c_str(), delta, win.c_str(), hexf(d.thr).c_str(), win.c_str());
+      out.compute += e + vote;
+      out.base = (double)d.right;
+      out.base_q = rq;
+    } else if (delta_form) {  // vote = right + (v < thr ? left - right : 0): the constant `right` is added once per part
       char delta[64];  // (hexf reuses `buf`)
       snprintf(delta, sizeof(delta), "%a", (double)d.left - (double)d.right);
       out.compute += e + "; v *= vnf" + win + "; acc" + win + " += (v < " + hexf(d.thr) + " ? " + delta + " : 0.); }";
@@ -1053,9 +1101,17 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
       snprintf(buf, sizeof(buf), "    case %d: {\n", s);
       o += buf;
       std::vector<SpecStump> st;
+      double q = 0.;
+      const bool fixed = delta_form && fixed_point_ok && stage_quantum(s, q);
       for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++)
-        st.push_back(stump(t[step - 1][(size_t)m.stage_first[(size_t)s] + i], m.stage_first[(size_t)s] + i, i, ""));
-      spec_emit_stage(o, st, depth, true, {"acc"});
+        st.push_back(stump(t[step - 1][(size_t)m.stage_first[(size_t)s] + i], m.stage_first[(size_t)s] + i, i, "", fixed ? q : 0.));
+      if (fixed) {
+        o += "      unsigned ai = 0u;\n";
+        spec_emit_stage(o, st, depth, true, {"ai"}, true);
+        snprintf(buf, sizeof(buf), "      acc = (double)(int)ai * %a;\n", q);
+        o += buf;
+      } else
+        spec_emit_stage(o, st, depth, true, {"acc"});
       o += "    } break;\n";
     }
     o += "    default: break;\n  }\n  return acc;\n}\n";
@@ -1067,12 +1123,20 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
     o += buf;
     {
       std::vector<SpecStump> st;
+      double q = 0.;
+      const bool fixed = delta_form && fixed_point_ok && stage_quantum(0, q);
       for (int i = 0; i < m.stage_ntrees[0]; i++) {
         const HaarStumpDev& d = t[step - 1][(size_t)m.stage_first[0] + i];
-        SpecStump a = stump(d, m.stage_first[0] + i, i, "a"), b2 = stump(d, m.stage_first[0] + i, i, "b");
-        st.push_back(SpecStump{a.loads + b2.loads, a.decls + " " + b2.decls, a.compute + " " + b2.compute, a.base});
+        SpecStump a = stump(d, m.stage_first[0] + i, i, "a", fixed ? q : 0.), b2 = stump(d, m.stage_first[0] + i, i, "b", fixed ? q : 0.);
+        st.push_back(SpecStump{a.loads + b2.loads, a.decls + " " + b2.decls, a.compute + " " + b2.compute, a.base, a.base_q});
       }
-      spec_emit_stage(o, st, depth, false, {"acca", "accb"});
+      if (fixed) {
+        o += "      unsigned aia = 0u, aib = 0u;\n";
+        spec_emit_stage(o, st, depth, false, {"aia", "aib"}, true);
+        snprintf(buf, sizeof(buf), "      acca = (double)(int)aia * %a;\n      accb = (double)(int)aib * %a;\n", q, q);
+        o += buf;
+      } else
+        spec_emit_stage(o, st, depth, false, {"acca", "accb"});
     }
     o += "  }\n  acc_a = acca;\n  acc_b = accb;\n}\n";
   }
