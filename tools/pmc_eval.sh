@@ -27,8 +27,8 @@ for k,v in agg.items():
         out = {"kernel": k, "kernel_src_sha16": kernel_source_sha16(), "counters_per_launch": {c: round(x) for c, x in m.items()},
                "kernel_cycles": round(cyc), "lds_pipeline_busy": round(m["SQ_LDS_IDX_ACTIVE"] / cus / cyc, 3),
                "lds_bank_conflict_share": round(m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"], 3),
-               "valu_busy": round(m["SQ_INSTS_VALU"] * 4 / simds / cyc, 3),
-               "how": "rocprofv3 --kernel-trace --pmc (one pass, no stream overlap), bench.py --cpu-frames 0 --steps 2 --warmup 1; LDS busy = SQ_LDS_IDX_ACTIVE / 256 CUs / kernel cycles (GRBM_GUI_ACTIVE / 8 XCDs); VALU busy = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / kernel cycles"}
+               "valu_busy": round(m["SQ_INSTS_VALU"] * 2.9 / simds / cyc, 3),
+               "how": "rocprofv3 --kernel-trace --pmc (one pass, no stream overlap), bench.py --cpu-frames 0 --steps 2 --warmup 1; LDS busy = SQ_LDS_IDX_ACTIVE / 256 CUs / kernel cycles (GRBM_GUI_ACTIVE / 8 XCDs); VALU busy = SQ_INSTS_VALU x 2.9 cycles / 1024 SIMDs / kernel cycles (2.9 = issue cost of the kernel's instruction mix from tools/pmc_microbench.sh: add/sub/mov/mul 2.4-2.7, cmp/cndmask 3.8, cvt 4.2, f64 4.8 cycles per wavefront instruction on a saturated SIMD; the nominal 4 cycles would read 1.48 on a saturated v_add_u32 stream)"}
         json.dump(out, open("$out/summary.json", "w"), indent=1)
         print("  LDS pipeline busy:", out["lds_pipeline_busy"], " VALU busy:", out["valu_busy"])
         if m.get("SQ_BUSY_CYCLES"):
