@@ -63,9 +63,27 @@ __device__ __forceinline__ int find_segment(const int* __restrict__ first, int n
 // row are reused when the next output row starts on it (the usual case below scale 2), so an output pixel costs about
 // one new source row (2 byte loads) instead of two rows and two table lookups.
 // ------------------------------------------------------------------------------------------------
+// A block is 4 wavefronts = 4 consecutive bands of RESIZE_ROWS output rows x 64 words (256 columns): a wavefront stays
+// inside one band, so its row taps are wave-uniform (scalar loads).
 constexpr int RESIZE_ROWS = 8;
+struct __attribute__((packed, aligned(1))) Bytes16 {  // 16 bytes at any address (the hardware takes unaligned global loads)
+  unsigned d[4];
+};
 __host__ __device__ inline int resize_blocks(int pitch8, int h) {
-  return ((pitch8 / 4) * ((h + RESIZE_ROWS - 1) / RESIZE_ROWS) + 255) / 256;
+  return ((pitch8 / 4 + 63) / 64) * (((h + RESIZE_ROWS - 1) / RESIZE_ROWS + 3) / 4);
+}
+// Appends one scale's column taps, padded with copies of the last tap to a multiple of 4 entries (so does every earlier
+// scale: the returned offset is a multiple of 4): a thread fetches the taps of its 4 columns with one 16-byte and one
+// 8-byte load, and the columns of the row padding get the last column's taps (their output is masked anyway).
+static int append_column_taps(const AxisTaps& t, std::vector<int>& ofs, std::vector<uint16_t>& w1) {
+  const int at = (int)ofs.size();
+  ofs.insert(ofs.end(), t.ofs.begin(), t.ofs.end());
+  w1.insert(w1.end(), t.w1.begin(), t.w1.end());
+  while (ofs.size() % 4) {
+    ofs.push_back(t.ofs.back());
+    w1.push_back(t.w1.back());
+  }
+  return at;
 }
 
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ frames, size_t row_stride, size_t frame_stride,
@@ -76,26 +94,54 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ fram
                                                 const uint16_t* __restrict__ yw1) {
   const int s = find_segment(blk_first, nscales, blockIdx.x);
   const ScaleDev S = sd[s];
-  const int wpr = S.pitch8 >> 2;
-  const int item = (blockIdx.x - blk_first[s]) * 256 + threadIdx.x;
-  const int band = item / wpr, xw = item - band * wpr;
+  const int wpr = S.pitch8 >> 2, nxb = (wpr + 63) >> 6;
+  const int bi = blockIdx.x - blk_first[s];
+  const int bb = bi / nxb, xb = bi - bb * nxb;
+  const int band = bb * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), xw = xb * 64 + (threadIdx.x & 63);
   const int ya = band * RESIZE_ROWS;
-  if (ya >= S.h) return;
+  if (ya >= S.h || xw >= wpr) return;
   const uint8_t* src = frames + (size_t)blockIdx.y * frame_stride;
   int x0[4], x1[4];
   unsigned wx0[4], wx1[4];
+  {  // taps of columns 4 xw .. 4 xw + 3 (the tables are padded to the row pitch, see append_column_taps)
+    const int4 o = *reinterpret_cast<const int4*>(xofs + S.xtab_ofs + xw * 4);
+    const uint2 w = *reinterpret_cast<const uint2*>(xw1 + S.xtab_ofs + xw * 4);
+    x0[0] = o.x, x0[1] = o.y, x0[2] = o.z, x0[3] = o.w;
+    wx1[0] = w.x & 0xFFFFu, wx1[1] = w.x >> 16, wx1[2] = w.y & 0xFFFFu, wx1[3] = w.y >> 16;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      wx0[k] = 256u - wx1[k];
+      x1[k] = min(x0[k] + 1, src_w - 1);
+    }
+  }
+  // Up to scale ~4.6 the 8 source bytes a row contributes to the thread's 4 columns lie within 16 bytes: they come in
+  // with ONE (unaligned) 16-byte load from `start` and are picked out with byte permutes whose selectors are fixed per
+  // thread -- instead of 8 single-byte loads per source row, which is what the kernel's time went into.
+  const int start = min(x0[0], src_w - 16);  // x0 / x1 do not decrease with k: x0[0] is the first, x1[3] the last byte
+  const bool wide = src_w >= 16 && x1[3] - start <= 15;
+  unsigned sel0 = 0, sel1 = 0, low0 = 0, low1 = 0;  // per tap: byte index within its 8-byte half, 0xFF where it is the low half
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int x = min(xw * 4 + k, S.w - 1);  // columns past the image (row padding) are masked out below
-    x0[k] = xofs[S.xtab_ofs + x];
-    wx1[k] = xw1[S.xtab_ofs + x];
-    wx0[k] = 256u - wx1[k];
-    x1[k] = min(x0[k] + 1, src_w - 1);
+    const int o0 = x0[k] - start, o1 = x1[k] - start;
+    sel0 |= (unsigned)(o0 & 7) << (8 * k);
+    sel1 |= (unsigned)(o1 & 7) << (8 * k);
+    low0 |= (o0 < 8 ? 0xFFu : 0u) << (8 * k);
+    low1 |= (o1 < 8 ? 0xFFu : 0u) << (8 * k);
   }
   auto hrow = [&](int yy, unsigned* h) {  // horizontal interpolation of source row yy at the 4 columns
     const uint8_t* r = src + (size_t)yy * row_stride;
+    if (wide) {
+      const Bytes16 v = *reinterpret_cast<const Bytes16*>(r + start);
+      // __builtin_amdgcn_perm(hi, lo, sel): byte j of the result = byte sel[j] (0..7) of the 8 bytes {lo, hi}
+      const unsigned a_lo = __builtin_amdgcn_perm(v.d[1], v.d[0], sel0), a_hi = __builtin_amdgcn_perm(v.d[3], v.d[2], sel0);
+      const unsigned b_lo = __builtin_amdgcn_perm(v.d[1], v.d[0], sel1), b_hi = __builtin_amdgcn_perm(v.d[3], v.d[2], sel1);
+      const unsigned t0 = (a_lo & low0) | (a_hi & ~low0), t1 = (b_lo & low1) | (b_hi & ~low1);
 #pragma unroll
-    for (int k = 0; k < 4; k++) h[k] = wx0[k] * r[x0[k]] + wx1[k] * r[x1[k]];
+      for (int k = 0; k < 4; k++) h[k] = wx0[k] * ((t0 >> (8 * k)) & 255u) + wx1[k] * ((t1 >> (8 * k)) & 255u);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) h[k] = wx0[k] * r[x0[k]] + wx1[k] * r[x1[k]];
+    }
   };
   unsigned hc[4] = {0, 0, 0, 0};
   int cached = -1;  // source row whose interpolation hc holds
@@ -1402,13 +1448,11 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
     S.scale = g.scale;
     S.win_w = g.win_w;
     S.win_h = g.win_h;
-    S.xtab_ofs = (int)xofs.size();
     S.ytab_ofs = (int)yofs.size();
     AxisTaps tx, ty;
     linear_exact_taps(w, g.w, tx);
     linear_exact_taps(h, g.h, ty);
-    xofs.insert(xofs.end(), tx.ofs.begin(), tx.ofs.end());
-    xw1.insert(xw1.end(), tx.w1.begin(), tx.w1.end());
+    S.xtab_ofs = append_column_taps(tx, xofs, xw1);
     yofs.insert(yofs.end(), ty.ofs.begin(), ty.ofs.end());
     yw1.insert(yw1.end(), ty.w1.begin(), ty.w1.end());
     img_ofs += (long long)align_up(S.pitch8 * g.h, 16);
@@ -2566,6 +2610,9 @@ cc_status cc_resize_linear_exact_u8(int device, const uint8_t* src, int sw, int 
   AxisTaps tx, ty;
   linear_exact_taps(sw, dw, tx);
   linear_exact_taps(sh, dh, ty);
+  std::vector<int> xofs_pad;
+  std::vector<uint16_t> xw1_pad;
+  S.xtab_ofs = append_column_taps(tx, xofs_pad, xw1_pad);
   std::vector<ScaleDev> sd{S};
   const int nblk = resize_blocks(S.pitch8, dh);
   std::vector<int> first{0, nblk};
@@ -2576,9 +2623,9 @@ cc_status cc_resize_linear_exact_u8(int device, const uint8_t* src, int sw, int 
   const size_t spitch = (size_t)align_up(sw, 4);
   CC_HIP(d_sd.upload(sd, nullptr));
   CC_HIP(d_first.upload(first, nullptr));
-  CC_HIP(d_xofs.upload(tx.ofs, nullptr));
+  CC_HIP(d_xofs.upload(xofs_pad, nullptr));
   CC_HIP(d_yofs.upload(ty.ofs, nullptr));
-  CC_HIP(d_xw1.upload(tx.w1, nullptr));
+  CC_HIP(d_xw1.upload(xw1_pad, nullptr));
   CC_HIP(d_yw1.upload(ty.w1, nullptr));
   CC_HIP(d_src.ensure(spitch * sh));
   CC_HIP(d_dst.ensure((size_t)S.pitch8 * dh));
@@ -2816,13 +2863,11 @@ cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int he
     S.int_ofs = int_ofs;
     S.h_ofs = h_ofs;
     S.nbands = (S.h + INT_BAND - 1) / INT_BAND;
-    S.xtab_ofs = (int)xofs.size();
     S.ytab_ofs = (int)yofs.size();
     AxisTaps tx, ty;
     linear_exact_taps(width, S.w, tx);
     linear_exact_taps(height, S.h, ty);
-    xofs.insert(xofs.end(), tx.ofs.begin(), tx.ofs.end());
-    xw1.insert(xw1.end(), tx.w1.begin(), tx.w1.end());
+    S.xtab_ofs = append_column_taps(tx, xofs, xw1);
     yofs.insert(yofs.end(), ty.ofs.begin(), ty.ofs.end());
     yw1.insert(yw1.end(), ty.w1.begin(), ty.w1.end());
     MineLevel& L = lv[(size_t)i];
