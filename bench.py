@@ -292,12 +292,13 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "i32+f32 (f64 stage sums)",
+        "dtype": "i32+f32 (f64 stage sums)" if inf["feature_type"] == 0 else "i32 (f64 stage sums)",
         "data": "synthetic",
         "config": {
-            "workload": f"{W}x{H} Haar frontalface detection, full scale pyramid (scaleFactor {args.scale_factor}, minNeighbors "
+            "workload": f"{W}x{H} {'Haar' if inf['feature_type'] == 0 else 'LBP'} frontalface detection, full scale pyramid (scaleFactor {args.scale_factor}, minNeighbors "
                         f"{args.min_neighbors}), {len(plan)} scales, {windows_per_frame} grid windows/frame",
-            "cascade": os.path.basename(args.cascade) + " (synthetic, stock 25-stage/2913-stump profile)",
+            "cascade": os.path.basename(args.cascade) + f" ({inf['n_stages']} stages, {inf['n_weak']} weak classifiers"
+                       + ("; synthetic, stock 25-stage/2913-stump profile)" if "synthetic" in os.path.basename(args.cascade) else ")"),
             "visited_windows_frame0": visited0,
             "kernel_specialized_stages": spec_stages,
             "frames_per_gpu_per_step": B,

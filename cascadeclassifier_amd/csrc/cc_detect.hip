@@ -921,8 +921,7 @@ struct SpecStump {
   long long base_q = 0; // the same in units of the stage's quantum (fixed-point form)
 };
 
-static int spec_prefetch_depth() {
-  int d = 2;
+static int spec_prefetch_depth(int d = 2) {
   if (const char* e = std::getenv("CCAMD_SPEC_PREFETCH")) d = std::max(0, std::min(4, std::atoi(e)));  // tuning
   return d;
 }
@@ -1196,7 +1195,7 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages) {
   build_lbp_stumps<1>(m, t[0]);
   build_lbp_stumps<2>(m, t[1]);
   n_stages = std::min<int>(n_stages, (int)m.stage_ntrees.size());
-  const int depth = std::min(spec_prefetch_depth(), 2);  // 16 words per stump in flight
+  const int depth = std::min(spec_prefetch_depth(0), 2);  // 16 independent words per stump already: no explicit pipelining measured best (7.8 ms per 32 frames; one stump ahead 8.2, two 8.9)
   std::string o;
   char buf[1024];
   int n_stumps = 0;
