@@ -45,6 +45,32 @@ def test_specialised_stock_profile_cascade(haar_xml, k):
     assert all(a.shape == b.shape and (a == b).all() for a, b in zip(spec, plain))
 
 
+def test_specialised_mixed_fixed_point_and_double_stages(haar_xml, tmp_path):
+    """The generated stages accumulate votes as int32 multiples of the stage's leaf quantum where the sums fit and as
+    doubles otherwise. A tiny leaf (quantum 2^-45) in stages 1 and 3 of the stock-profile cascade pushes those two out of
+    the integer form while their neighbours keep it: results must still match the oracle bit for bit."""
+    import re
+    text = open(haar_xml).read()
+    sizes = [int(v) for v in re.findall(r"<maxWeakCount>(\d+)</maxWeakCount>", text[text.index("<stages>"):])]
+    leaves = list(re.finditer(r"<leafValues>\s*(\S+)\s+(\S+)</leafValues>", text))
+    assert len(leaves) == sum(sizes)
+    edits = {sum(sizes[:1]) + 2: ("3.1e-07", "-3.1e-07"), sum(sizes[:3]) + 5: ("-2.9e-07", "4.4e-07")}
+    out, last = [], 0
+    for i, mt in enumerate(leaves):
+        if i in edits:
+            out.append(text[last:mt.start()] + "<leafValues>%s %s</leafValues>" % edits[i])
+            last = mt.end()
+    text = "".join(out) + text[last:]
+    path = str(tmp_path / "mixed.xml")
+    open(path, "w").write(text)
+    o = orc.load_cascade_xml(path)
+    p = cc.CascadeClassifier(path)
+    assert p.specialize(7) == 7
+    n = _same_as_oracle(p, o, frame_natural(640, 360, 11), 1.1)
+    n += _same_as_oracle(p, o, frame_uniform(300, 200, 12), 1.25)
+    assert n > 0
+
+
 def test_specialised_tilted_and_other_windows(tmp_path):
     img = frame_natural(320, 240, 3)
     cal = np.stack([img[y:y + 24, x:x + 24] for y in range(0, 200, 9) for x in range(0, 280, 11)])
