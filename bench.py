@@ -85,6 +85,55 @@ def corner_reads_frame0(clf, frame, scale_factor):
     return int(reads[vis != 0].sum())
 
 
+def measure_extra_workload(cc, torch, dev, dev_index, cascade, specialize, frames_host, args, label):
+    """One of the post-headline workloads (rank 0, N = 1; outside the headline's timed region): the same step as the
+    headline -- resident frames, whole detection path incl. copy-back + grouping -- for another cascade / frame content.
+    Returns value, kernel time, HBM and LDS roofline fractions, and whether the CPU oracle's rectangles agree on frame 0."""
+    import numpy as np
+    B, H, W = frames_host.shape
+    frames = torch.from_numpy(frames_host).to(dev)
+    clf = cc.CascadeClassifier(cascade, device=dev_index, max_batch=B)
+    inf = clf.info()
+    spec = 0
+    if specialize > 0 and inf["max_nodes_per_tree"] == 1:
+        try:
+            spec = clf.specialize(specialize)
+        except cc.CascadeError as e:
+            print(f"[bench] {label}: specialisation unavailable: {e}", file=sys.stderr)
+    plan = cc.scale_plan(inf["win_w"], inf["win_h"], W, H, args.scale_factor)
+    wpf = int((plan["nx"].astype(np.int64) * plan["ny"]).sum())
+    ipx = int(((plan["w"] + 1).astype(np.int64) * (plan["h"] + 1)).sum())
+    bytes_frame = (8 if inf["feature_type"] == 0 else 4) * ipx
+
+    def step():
+        return clf.detect_batch(None, args.scale_factor, args.min_neighbors, device_ptr=frames.data_ptr(), shape=(B, H, W))
+    step()
+    clf.set_profiling(True)
+    clf.timings(reset=True)
+    torch.cuda.synchronize()
+    steps = max(2, min(args.steps, 4))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tm = clf.timings(reset=True)
+    clf.set_profiling(False)
+    eval_ms = tm["eval_ms"] / max(tm["eval_launches"], 1)
+    fpl = tm["frames"] / max(tm["eval_launches"], 1)
+    ach = bytes_frame * fpl / (eval_ms * 1e-3) / 1e9 if eval_ms > 0 else 0.0
+    reads0 = corner_reads_frame0(clf, frames_host[0], args.scale_factor)
+    lds_ach = reads0 * 4 * fpl / (eval_ms * 1e-3) / 1e9 if eval_ms > 0 else 0.0
+    from oracle import oracle as orc
+    want = orc.detect_multiscale(orc.load_cascade_xml(cascade), frames_host[0], args.scale_factor, args.min_neighbors, nthreads=usable_cores())
+    same = want.shape == last[0].shape and bool((want == last[0]).all())
+    del clf
+    return {"workload": label, "value": round(wpf * B * steps / dt / 1e6, 3), "unit": "Mwindows/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "steps": steps, "frames_per_step": B, "kernel_specialized_stages": spec, "cascade_kernel_ms_per_launch": round(eval_ms, 4),
+            "frames_per_launch": fpl, "roofline_frac_hbm": round(ach / HBM_PEAK_GBS, 5), "achieved_GBps": round(ach, 2),
+            "lds_frac": round(lds_ach / (256 * 128 * 2.4), 4), "rectangles_identical_to_cpu_oracle_frame0": same}
+
+
 def spawn_ranks(n):
     """Starts n copies of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, 127.0.0.1 rendezvous on a free port) and
     waits for them. Returns the first non-zero exit status, or 0. If one rank dies the others are terminated, so a
@@ -133,6 +182,9 @@ def main():
     ap.add_argument("--specialize", type=int, default=7, help="stages compiled into the cascade kernel at load time (hiprtc; 0 = "
                                                               "table-driven kernel only)")
     ap.add_argument("--device-only", action="store_true", help="time the device pipeline only (no copy-back/grouping)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the legs reported beside the headline (host split, host-frame "
+                                                          "call shape, LBP cascade, uniform-noise frames); rank 0 at N = 1 only")
+    ap.add_argument("--cpu-reps", type=int, default=5, help="repetitions of the CPU-baseline sample (median is reported)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -234,6 +286,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # Where the step time goes that is not kernel time: the same step without copy-back and grouping (device pipeline
+    # only), and the step fed from HOST frames (the reference's call shape, tools/detection/Cpp/main.cpp:27-45: the image is
+    # in host memory; H2D copies included). Both outside the headline's timed region; rank 0, N = 1.
+    extra_legs = rank == 0 and world == 1 and not args.device_only and not args.no_extra
+    host_split = None
+    host_frames_leg = None
+    if extra_legs:
+        k = max(2, min(args.steps, 5))
+        clf.run_device_only(frames.data_ptr(), (B, H, W), args.scale_factor)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            clf.run_device_only(frames.data_ptr(), (B, H, W), args.scale_factor)
+        torch.cuda.synchronize()
+        dev_ms = (time.perf_counter() - t1) / k * 1e3
+        host_split = {"device_pipeline_only_ms_per_step": round(dev_ms, 4),
+                      "host_ms_per_step": round(dt / args.steps * 1e3 - dev_ms, 4),
+                      "what": "ms_per_step minus the same step without candidate copy-back, host grouping and Python list building (device "
+                              f"pipeline only, {k} steps after the timed region); the device legs of the passes overlap, so kernel_ms_per_step does not add up to either"}
+        clf.detect_batch(frames_host, args.scale_factor, args.min_neighbors)
+        t1 = time.perf_counter()
+        for _ in range(k):
+            clf.detect_batch(frames_host, args.scale_factor, args.min_neighbors)
+        hdt = (time.perf_counter() - t1) / k
+        host_frames_leg = {"ms_per_step": round(hdt * 1e3, 4), "value": round(windows_per_frame * B / hdt / 1e6, 3), "unit": "Mwindows/s",
+                           "what": f"the same step with the {B} frames in pageable host memory (H2D copies inside the call, {k} steps): the reference's "
+                                   "call shape; never the headline `value`"}
+
     # windows the scan actually visits (grid windows minus the positions the stage-0 skip rule jumps over), frame 0,
     # outside the timed region (SURVEY.md §8d asks for it next to the grid count)
     visited0 = None
@@ -310,6 +390,8 @@ def main():
         },
         "frames_per_s": round(B * world * args.steps / dt, 2),
         "kernel_ms_per_step": {k: round(tm[k] / args.steps, 4) for k in ("resize_ms", "integral_ms", "eval_ms", "finalize_ms")},
+        "host_split": host_split,
+        "host_frames": host_frames_leg,
         "roofline": {
             "kernel": kernel_name,
             "bound": "hbm",
@@ -323,7 +405,9 @@ def main():
             "frames_per_launch": frames_per_launch,
             "avg_launch_ms": round(eval_ms, 4),
             "kernel_src_sha16": src_sha,
-            "limiter": "LDS corner gathers + VALU issue, not HBM (see lds and secondary)",
+            "bound_is": "the roofline SURVEY.md 8d prices this kernel against (HBM bytes: every integral entry once); it is NOT what "
+                        "limits the kernel",
+            "practical_limiter": "VALU issue and LDS corner gathers (about 50 stump evaluations per window): see lds, secondary and DESIGN.md 4.4",
             "lds": lds,
             "secondary": secondary,
         },
@@ -334,13 +418,16 @@ def main():
         cores = usable_cores()
         nfr = min(args.cpu_frames, B)
         orc.detect_multiscale(o, frames_host[0][:270, :480], args.scale_factor, args.min_neighbors, nthreads=cores)  # warm-up
-        t0 = time.perf_counter()
         ok = True
-        for i in range(nfr):
-            r = orc.detect_multiscale(o, frames_host[i], args.scale_factor, args.min_neighbors, nthreads=cores)
-            if last is not None:
-                ok = ok and r.shape == last[i].shape and bool((r == last[i]).all())
-        cdt = time.perf_counter() - t0
+        times = []
+        for rep in range(max(1, args.cpu_reps)):  # median of >= 5 repetitions after a warm-up
+            t0 = time.perf_counter()
+            for i in range(nfr):
+                r = orc.detect_multiscale(o, frames_host[i], args.scale_factor, args.min_neighbors, nthreads=cores)
+                if rep == 0 and last is not None:
+                    ok = ok and r.shape == last[i].shape and bool((r == last[i]).all())
+            times.append(time.perf_counter() - t0)
+        cdt = float(np.median(times))
         t1 = time.perf_counter()
         orc.detect_multiscale(o, frames_host[0], args.scale_factor, args.min_neighbors, nthreads=1)
         one = time.perf_counter() - t1
@@ -350,11 +437,30 @@ def main():
             "cores": cores,
             "kind": "port",
             "sample": f"{nfr} of the same {W}x{H} frames, full detectMultiScale, CPU oracle (restatement of the reference path; "
-                      f"OpenCV not installed), {cores} threads over grid rows",
+                      f"OpenCV not installed), {cores} threads over grid rows; median of {len(times)} repetitions after a warm-up call",
             "seconds": round(cdt, 2),
+            "seconds_all_repetitions": [round(t, 2) for t in times],
             "value_1_thread": round(windows_per_frame / one / 1e6, 3),
+            "value_1_thread_sample": "frame 0 once",
             "rectangles_identical_to_gpu": ok if last is not None else None,
         }
+    # The workloads SURVEY.md 8d lists beside the headline, each as a short run of the same step (rank 0, N = 1): the stock
+    # LBP cascade (BASELINE configs[2]) and the headline cascade on i.i.d. uniform noise (distribution (i)).
+    if extra_legs:
+        del clf
+        extras = []
+        lbp = os.path.join(ROOT, "data", "lbpcascade_frontalface.xml")
+        try:
+            if os.path.abspath(args.cascade) != lbp and os.path.exists(lbp):
+                extras.append(measure_extra_workload(cc, torch, dev, dev_index, lbp, 20, frames_host, args,
+                                                     f"{W}x{H} LBP frontalface (stock lbpcascade_frontalface.xml), same frames -- BASELINE configs[2]"))
+            if args.content != "uniform":
+                extras.append(measure_extra_workload(cc, torch, dev, dev_index, args.cascade, args.specialize,
+                                                     make_frames(B, W, H, seed0=0, content="uniform"), args,
+                                                     f"{W}x{H} headline cascade on i.i.d. uniform noise (SURVEY 8d distribution (i))"))
+        except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
+            extras.append({"error": str(e)})
+        out["extra_workloads"] = extras
     if rank == 0:
         print(json.dumps(out))
     if comm is not None:
@@ -363,6 +469,8 @@ def main():
         dist.destroy_process_group()
     if out.get("cpu_baseline", {}).get("rectangles_identical_to_gpu") is False:
         sys.exit("bench.py: GPU rectangles differ from the CPU oracle on the baseline sample: the number above is invalid")
+    if any(e.get("rectangles_identical_to_cpu_oracle_frame0") is False for e in out.get("extra_workloads", [])):
+        sys.exit("bench.py: an extra workload's GPU rectangles differ from the CPU oracle")
 
 
 if __name__ == "__main__":

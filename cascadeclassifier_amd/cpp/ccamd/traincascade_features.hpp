@@ -123,6 +123,7 @@ class CvFeatureEvaluator {  // traincascade_features.h:155-188
   int maxSampleCount;
   unsigned generation;  // bumped by every setImage: invalidates cached feature values
   unsigned long long uid;  // unique per init(): the per-thread value caches belong to one initialised evaluator
+  int lastSetIdx;          // sample index of the most recent setImage (a prediction walk asks for that sample)
 
   // setImage() calls are queued on the host and reach the device as ONE cc_eval_set_images per run of consecutive
   // indices, when something first reads (the positives / negatives of a stage are set one by one:

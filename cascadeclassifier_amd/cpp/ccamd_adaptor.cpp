@@ -9,6 +9,7 @@
 #include <iostream>
 
 #include "ccamd/traincascade_features.hpp"
+#include "ccamd/value_cache_policy.hpp"
 
 namespace {
 
@@ -31,28 +32,15 @@ inline void check(cc_status st, const char* where) {
   if (st != CC_OK) throw_last(where);
 }
 
-// Per-thread caches behind the scalar operator()(fi, si). The trainer calls it in two shapes:
-//  * one feature over many samples (precalculate, get_ord_var_data: o_cvcascadeboosttraindata.cpp:403-458,490-596):
-//    a miss evaluates the whole ROW fi on the device (one launch per feature);
-//  * many features of one freshly set sample (stage prediction during negative mining: cascadeclassifier.cpp:340-347 ->
-//    boost.cpp:461-477 -> getVarValue): the features asked for are the cascade's, the same list window after window. The
-//    cache learns that list and a miss evaluates the whole list for the sample in ONE launch (cc_eval_calc_list), so a
-//    window costs one device evaluation instead of one per weak classifier.
-// Which shape a miss belongs to is read off the previous miss: same sample, other feature -> list shape.
+// Per-thread caches behind the scalar operator()(fi, si): the bookkeeping (which access hits, what a miss launches) is
+// ccamd::ValueCacheIndex (ccamd/value_cache_policy.hpp), the values live here.
 struct ValueCache {
-  unsigned long long owner = 0;  // uid of the evaluator the cached values and the learned list belong to
-  unsigned generation = 0;
-  int row_fi = -1;  // row cache
-  std::vector<float> row;
-  int col_si = -1;  // list ("column") cache
-  std::vector<int32_t> list;  // learned feature list, in first-seen order
-  std::vector<int32_t> slot;  // feature index -> position in `list` (-1 = not in it), sized on first use
-  std::vector<float> col;
-  int last_fi = -1, last_si = -1;  // previous miss
+  ccamd::ValueCacheIndex ix;
+  std::vector<float> row;  // values of feature ix.row_fi for every sample
+  std::vector<float> col;  // values of the learned list ix.list for sample ix.list_si
 };
 thread_local ValueCache g_cache;
 std::atomic<unsigned long long> g_next_uid{1};
-constexpr size_t kMaxLearnedFeatures = 16384;
 
 }  // namespace
 
@@ -405,7 +393,7 @@ struct CvFeatureEvaluator::Pending {
 };
 
 CvFeatureEvaluator::CvFeatureEvaluator()
-    : npos(0), nneg(0), numFeatures(0), featureParams(nullptr), h(nullptr), maxSampleCount(0), generation(0), uid(0), pending(nullptr) {}
+    : npos(0), nneg(0), numFeatures(0), featureParams(nullptr), h(nullptr), maxSampleCount(0), generation(0), uid(0), lastSetIdx(-1), pending(nullptr) {}
 
 CvFeatureEvaluator::~CvFeatureEvaluator() {
   delete pending;
@@ -456,6 +444,7 @@ void CvFeatureEvaluator::setImage(const cv::Mat& img, uchar clsLabel, int idx) {
   }
   cls.at<float>(idx, 0) = (float)clsLabel;  // getCls() answers from host memory at once (features.cpp:88)
   generation++;
+  lastSetIdx = idx;
 }
 
 void CvFeatureEvaluator::flushImages() const {
@@ -471,6 +460,7 @@ void CvFeatureEvaluator::setImages(const uchar* imgs, int n, int first_idx, cons
   flushImages();
   check(cc_eval_set_images(h, imgs, n, first_idx, labels), "CvFeatureEvaluator::setImages");
   generation++;
+  lastSetIdx = first_idx + n - 1;
 }
 
 void CvFeatureEvaluator::calcBatch(int fiBegin, int fiEnd, const int* sampleIdx, int nSamples, float* out) const {
@@ -502,43 +492,23 @@ float CvFeatureEvaluator::cachedValue(int featureIdx, int sampleIdx) const {
   CV_Assert(sampleIdx >= 0 && sampleIdx < maxSampleCount);
   CV_Assert(featureIdx >= 0 && featureIdx < numFeatures);
   ValueCache& c = g_cache;
-  if (c.owner != uid) {  // another evaluator used this thread before: forget everything, including the learned list
-    c = ValueCache();
-    c.owner = uid;
-    c.generation = generation;
+  switch (c.ix.access(featureIdx, sampleIdx, uid, generation, lastSetIdx, numFeatures)) {
+    case ccamd::ValueCacheIndex::HIT_ROW:
+      return c.row[(size_t)sampleIdx];
+    case ccamd::ValueCacheIndex::HIT_LIST:
+      return c.col[(size_t)c.ix.list_slot(featureIdx)];
+    case ccamd::ValueCacheIndex::MISS_LIST:
+      flushImages();
+      c.col.resize(c.ix.list.size());
+      check(cc_eval_calc_list(h, c.ix.list.data(), (int)c.ix.list.size(), sampleIdx, c.col.data()), "CvFeatureEvaluator::operator()");
+      return c.col[(size_t)c.ix.list_slot(featureIdx)];
+    case ccamd::ValueCacheIndex::MISS_ROW:
+    default:
+      flushImages();
+      c.row.resize((size_t)maxSampleCount);
+      check(cc_eval_calc_batch(h, featureIdx, featureIdx + 1, nullptr, maxSampleCount, c.row.data(), 0), "CvFeatureEvaluator::operator()");
+      return c.row[(size_t)sampleIdx];
   }
-  if (c.generation != generation) {  // samples changed: values are stale, the learned list is not
-    c.generation = generation;
-    c.row_fi = -1;
-    c.col_si = -1;
-  }
-  if (c.row_fi == featureIdx) return c.row[(size_t)sampleIdx];
-  if (c.col_si == sampleIdx && !c.slot.empty() && c.slot[(size_t)featureIdx] >= 0) return c.col[(size_t)c.slot[(size_t)featureIdx]];
-  flushImages();
-  const bool list_shape = c.last_si == sampleIdx && c.last_fi != featureIdx && c.last_fi >= 0;
-  auto learn = [&](int fi) {
-    if (c.slot.empty()) c.slot.assign((size_t)numFeatures, -1);
-    if (c.slot[(size_t)fi] < 0 && c.list.size() < kMaxLearnedFeatures) {
-      c.slot[(size_t)fi] = (int32_t)c.list.size();
-      c.list.push_back(fi);
-    }
-  };
-  c.last_fi = featureIdx;
-  c.last_si = sampleIdx;
-  if (list_shape) {
-    learn(featureIdx);
-    if (c.slot[(size_t)featureIdx] >= 0) {
-      c.col.resize(c.list.size());
-      check(cc_eval_calc_list(h, c.list.data(), (int)c.list.size(), sampleIdx, c.col.data()), "CvFeatureEvaluator::operator()");
-      c.col_si = sampleIdx;
-      return c.col[(size_t)c.slot[(size_t)featureIdx]];
-    }
-  }
-  learn(featureIdx);  // a later list-shaped miss evaluates this feature along with the others
-  c.row.resize((size_t)maxSampleCount);
-  check(cc_eval_calc_batch(h, featureIdx, featureIdx + 1, nullptr, maxSampleCount, c.row.data(), 0), "CvFeatureEvaluator::operator()");
-  c.row_fi = featureIdx;
-  return c.row[(size_t)sampleIdx];
 }
 
 cv::Ptr<CvFeatureEvaluator> CvFeatureEvaluator::create(int type) {  // features.cpp:91-97

@@ -733,6 +733,8 @@ struct cc_detector {
   hipStream_t own_stream = nullptr, stream = nullptr;
   // cascade tables on the device (one per tile layout)
   DevBuf<int> d_stage_ntrees, d_stage_first;
+  DevBuf<int> d_group_first;  // stage groups of the cascade kernel (EvalArgs::group_first), n_groups + 1 entries
+  int n_groups = 0;
   DevBuf<float> d_stage_thr;
   int wave_below = 0;
   int last_call_graph = 0;  // the last single-image call was one hipGraph launch (cc_detector_graph_active)
@@ -740,12 +742,17 @@ struct cc_detector {
   int split_stumps = 0;
   DevBuf<HaarStumpDev> d_haar1, d_haar2;
   DevBuf<HaarStumpDev> d_haar1w, d_haar2w;  // the same stumps dealt to lanes for the wave phase (bank-aware order)
+  DevBuf<HaarStumpDev> d_haar_g;            // corners as window coordinates (GlobalReader; kernels with 16-bit tiles)
+  DevBuf<LbpStumpDev> d_lbp_g;
   DevBuf<LbpStumpDev> d_lbp1, d_lbp2;
   DevBuf<HaarNodeDev> d_hnode1, d_hnode2;  // cascades with trees deeper than stumps
   DevBuf<LbpNodeDev> d_lnode1, d_lnode2;
   DevBuf<int> d_tree_root, d_tree_leaf0;
   DevBuf<float> d_leaves;
   size_t lds = 0;  // dynamic LDS bytes per tile (larger of the two layouts)
+  size_t lds_spec = 0;  // the same for the installed specialised kernel (smaller when its STEP-2 tiles hold 16-bit entries)
+  size_t lds_extra = 0; // CCAMD_DEBUG_EXTRA_LDS (occupancy experiments)
+  int spec_tile16 = 0;
   // plans + workspace
   std::vector<std::unique_ptr<Plan>> plans;
   DevBuf<uint8_t> d_frames, d_pyr;
@@ -766,6 +773,7 @@ struct cc_detector {
   std::atomic<int> spec_bg_state{0};  // 0 idle, 1 building, 2 ready to install, 3 failed
   std::vector<char> spec_bg_code;
   int spec_bg_stages = 0;
+  bool spec_bg_tile16 = false;
   std::string spec_bg_error;
   DevBuf<unsigned long long> d_masks;
   DevBuf<CandRaw> d_cands;
@@ -867,9 +875,11 @@ static bool stage_sums_order_independent(const Cascade& m, double headroom = 1.0
   return true;
 }
 
-template <int STEP>
-static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) {
-  const TileGeom<STEP> G(m.win_w, m.win_h);
+// `at(y, x)` maps a corner inside the window to what the record stores: an LDS offset of one of the tile layouts, or
+// (y << 16 | x) for the records whose corners are read from global memory (GlobalReader). tilt_shift: distance of the
+// tilted tile behind the sum tile.
+template <class At>
+static void build_haar_stumps_at(const Cascade& m, std::vector<HaarStumpDev>& out, At at, int tilt_shift) {
   out.resize(m.stump_feature.size());
   for (size_t i = 0; i < out.size(); i++) {
     HaarStumpDev& d = out[i];
@@ -885,16 +895,15 @@ static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) 
       if (j == 2 && wt != 0.0f) d.nrect = 3;
       const int x = used ? r[0] : 0, y = used ? r[1] : 0, rw = used ? r[2] : 0, rh = used ? r[3] : 0;
       if (!m.haar_tilted[fi]) {
-        d.ofs[j][0] = G.at(y, x);
-        d.ofs[j][1] = G.at(y, x + rw);
-        d.ofs[j][2] = G.at(y + rh, x);
-        d.ofs[j][3] = G.at(y + rh, x + rw);
+        d.ofs[j][0] = at(y, x);
+        d.ofs[j][1] = at(y, x + rw);
+        d.ofs[j][2] = at(y + rh, x);
+        d.ofs[j][3] = at(y + rh, x + rw);
       } else {  // corners of the 45-degree rectangle (CV_TILTED_OFFSETS), read from the tilted tile behind the sum tile
-        const int shift = tile_words_padded(G.words());
-        d.ofs[j][0] = shift + G.at(y, x);
-        d.ofs[j][1] = shift + G.at(y + rh, x - rh);
-        d.ofs[j][2] = shift + G.at(y + rw, x + rw);
-        d.ofs[j][3] = shift + G.at(y + rw + rh, x + rw - rh);
+        d.ofs[j][0] = tilt_shift + at(y, x);
+        d.ofs[j][1] = tilt_shift + at(y + rh, x - rh);
+        d.ofs[j][2] = tilt_shift + at(y + rw, x + rw);
+        d.ofs[j][3] = tilt_shift + at(y + rw + rh, x + rw - rh);
       }
     }
     d.thr = m.stump_threshold[i];
@@ -902,6 +911,13 @@ static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) 
     d.right = m.stump_right[i];
   }
 }
+template <int STEP>
+static void build_haar_stumps(const Cascade& m, std::vector<HaarStumpDev>& out) {
+  const TileGeom<STEP> G(m.win_w, m.win_h);
+  build_haar_stumps_at(m, out, [&](int y, int x) { return G.at(y, x); }, tile_words_padded(G.words()));
+}
+static int window_xy(int y, int x) { return (y << 16) | x; }  // GlobalReader records (upright features only)
+static void build_haar_gstumps(const Cascade& m, std::vector<HaarStumpDev>& out) { build_haar_stumps_at(m, out, window_xy, 0); }
 
 // Source text of spec_stage<1|2> (and spec_stage0_x2<1|2>) for the first n_stages stages: every stump becomes
 // straight-line code whose LDS offsets, weights, threshold and leaf values are literals (hex floats, exact). The
@@ -921,6 +937,14 @@ struct SpecStump {
   long long base_q = 0; // the same in units of the stage's quantum (fixed-point form)
 };
 
+// The generated stages are called from several places of the kernel (dense group, thread phase, stump-split slices).
+// Inlined everywhere, the code of every stage exists once per call site; as a real function it exists once (a third of
+// the instructions for the bench cascade) at the price of the call convention's register traffic. CCAMD_SPEC_NOINLINE picks.
+static const char* spec_stage_inline_attr() {
+  const char* e = std::getenv("CCAMD_SPEC_NOINLINE");
+  return (e && std::atoi(e) != 0) ? "__noinline__" : "__forceinline__";
+}
+
 static int spec_prefetch_depth(int d = 2) {
   if (const char* e = std::getenv("CCAMD_SPEC_PREFETCH")) d = std::max(0, std::min(4, std::atoi(e)));  // tuning
   return d;
@@ -934,13 +958,18 @@ static void spec_emit_stage(std::string& o, const std::vector<SpecStump>& st, in
   for (const SpecStump& t : st) o += "      " + t.decls + "\n";
   const int P = parts ? SPEC_PARTS : 1;
   char buf[128];
+  int prev_nonempty = -1;  // last part before k that holds stumps
   for (int k = 0; k < P; k++) {
     const int e0 = (int)((long long)k * nt / P), e1 = (int)((long long)(k + 1) * nt / P);
     if (e0 == e1) continue;
+    // The prologue (reads of the part's first `depth` stumps) belongs to the call whose range STARTS at this part -- or at
+    // one of the empty parts just before it: a stage with fewer stumps than SPEC_PARTS has empty parts, and a call that
+    // starts on one (the whole-stage call starts on part 0) must still issue the reads of the first stumps it evaluates.
     if (parts)
-      snprintf(buf, sizeof(buf), "      if (p_lo == %d) {\n", k);
+      snprintf(buf, sizeof(buf), "      if (p_lo > %d && p_lo <= %d) {\n", prev_nonempty, k);
     else
       snprintf(buf, sizeof(buf), "      {\n");
+    prev_nonempty = k;
     o += buf;
     for (int i = e0; i < std::min(e0 + depth, nt); i++) o += "      " + st[(size_t)i].loads + "\n" + kSB;
     o += "      }\n";
@@ -973,16 +1002,66 @@ static void spec_emit_stage(std::string& o, const std::vector<SpecStump>& st, in
   }
 }
 
-static std::string spec_stage_source_lbp(const Cascade& m, int n_stages);
+static std::string spec_stage_source_lbp(const Cascade& m, int n_stages, bool tile16);
 template <int STEP>
 static void build_lbp_stumps(const Cascade& m, std::vector<LbpStumpDev>& out);
+static void build_lbp_stumps16(const Cascade& m, std::vector<LbpStumpDev>& out);
 
-static std::string spec_stage_source(const Cascade& m, int n_stages) {
+// A rectangle sum read from 16-bit entries is exact when 255 * area < 2^16.
+static bool fits16(long long area) { return 255LL * area <= 65535LL; }
+
+// Cuts the rectangle (x, y, w, h) into the fewest strips along its longer side whose sums each fit 16 bits.
+static std::vector<std::array<int, 4>> pieces16(int x, int y, int w, int h) {
+  std::vector<std::array<int, 4>> out;
+  const bool along_x = w >= h;
+  const int len = along_x ? w : h;
+  for (int k = 1; k <= std::max(len, 1); k++) {
+    out.clear();
+    bool ok = true;
+    for (int i = 0; i < k; i++) {
+      const int a = (int)((long long)i * len / k), b = (int)((long long)(i + 1) * len / k);
+      if (a == b) continue;
+      const std::array<int, 4> pc = along_x ? std::array<int, 4>{x + a, y, b - a, h} : std::array<int, 4>{x, y + a, w, b - a};
+      ok = ok && fits16((long long)pc[2] * pc[3]);
+      out.push_back(pc);
+    }
+    if (ok) return out;
+  }
+  return {};  // a single row or column of the window does not fit: the caller's eligibility test has excluded this
+}
+
+// Can the first n_stages stages be generated for STEP-2 tiles with 16-bit entries (TileGeom16)? Upright Haar features
+// (any rectangle is cut into strips that fit) or LBP cells that fit; the variance rectangle is read as two halves.
+static bool tile16_eligible(const Cascade& m, int n_stages) {
+  // Opt-in (CCAMD_SPEC_TILE16=1): measured in round 3, the 16-bit tile raises the resident blocks per CU from 5 to 7
+  // and the thread-per-window stages gain 4 %, but the table-driven wave phase then reads its corners from global memory
+  // and loses twice that: the kernel as a whole is 15 % slower than with the 32-bit tile.
+  const char* on = std::getenv("CCAMD_SPEC_TILE16");
+  if (!on || std::atoi(on) == 0) return false;
+  if (m.max_nodes_per_tree > 1) return false;
+  n_stages = std::min<int>(n_stages, (int)m.stage_ntrees.size());
+  if (m.feature_type == CC_FEATURE_HAAR) {
+    if (m.has_tilted) return false;
+    const int nrx = m.win_w - 2, nry = m.win_h - 2;
+    if (nrx < 2 || !fits16((long long)(nrx - (nrx >> 1)) * nry)) return false;
+    if (!fits16(std::max(m.win_w, m.win_h))) return false;  // strips of one row / column always fit
+    return true;
+  }
+  for (int s = 0; s < n_stages; s++)
+    for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++) {
+      const int32_t* r = &m.lbp_rects[(size_t)m.stump_feature[(size_t)m.stage_first[(size_t)s] + i] * 4];
+      if (!fits16((long long)r[2] * r[3])) return false;
+    }
+  return true;
+}
+
+static std::string spec_stage_source(const Cascade& m, int n_stages, bool tile16) {
   const CNumericLocale c_numbers;  // "%a" literals must not follow the host program's LC_NUMERIC
-  if (m.feature_type == CC_FEATURE_LBP) return spec_stage_source_lbp(m, n_stages);
+  if (m.feature_type == CC_FEATURE_LBP) return spec_stage_source_lbp(m, n_stages, tile16);
   std::vector<HaarStumpDev> t[2];
   build_haar_stumps<1>(m, t[0]);
   build_haar_stumps<2>(m, t[1]);
+  const TileGeom16 G16(m.win_w, m.win_h);
   n_stages = std::min<int>(n_stages, (int)m.stage_ntrees.size());
   const int depth = spec_prefetch_depth();
   // Delta form of a vote: `(v < thr ? left : right)` needs both leaf values in registers (a select takes one literal), and
@@ -1026,8 +1105,9 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
     q = std::ldexp(1.0, emin - 24);  // every leaf is a multiple of q (see stage_sums_order_independent)
     return mag / q < 2147483647.0;
   };
-  auto stump = [&](const HaarStumpDev& d, int stump_index, int local, const std::string& win, double fixed_q) {
+  auto stump = [&](const HaarStumpDev& d, int stump_index, int local, const std::string& win, double fixed_q, bool h16) {
     const int fi = m.stump_feature[(size_t)stump_index];
+    const std::string tile_ptr = (h16 ? "h" : "b") + win;  // h<win>: the same tile base as 16-bit entries
     bool int_ok = true;
     double bound = 0;
     for (int j = 0; j < d.nrect; j++) {
@@ -1046,12 +1126,68 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
       const std::string name = buf;
       var[ofs] = name;
       out.decls += (out.decls.empty() ? "unsigned " : ", ") + name;
-      snprintf(buf, sizeof(buf), "%s = (unsigned)b%s[%d]; ", name.c_str(), win.c_str(), ofs);
+      snprintf(buf, sizeof(buf), "%s = (unsigned)%s[%d]; ", name.c_str(), tile_ptr.c_str(), ofs);
       out.loads += buf;
       return name;
     };
     std::string e = "{ float v = ";
-    if (int_ok) {
+    if (h16) {
+      // 16-bit tile (TileGeom16). Range of the integer value V = sum_j w_j * S_j over all images: pixel p contributes
+      // net(p) * I(p), I in [0, 255]. If [Vmin, Vmax] fits int16, V is the sign-extended low half of the same corner
+      // combination computed with the 16-bit entries (the dropped high halves only add multiples of 2^16). Otherwise
+      // every rectangle is summed exactly from strips whose sums fit 16 bits, and the strips' sums are combined in 32 bits.
+      long long vmin = 0, vmax = 0;
+      if (int_ok) {
+        std::vector<int> net((size_t)(m.win_w + 1) * (size_t)(m.win_h + 1), 0);
+        for (int j = 0; j < d.nrect; j++) {
+          const int32_t* r = &m.haar_rects[(size_t)fi * 12 + j * 4];
+          for (int yy = r[1]; yy < r[1] + r[3]; yy++)
+            for (int xx = r[0]; xx < r[0] + r[2]; xx++) net[(size_t)yy * (size_t)(m.win_w + 1) + (size_t)xx] += (int)d.w[j];
+        }
+        for (int v : net) (v > 0 ? vmax : vmin) += 255LL * v;
+      }
+      if (int_ok && vmin >= -32768 && vmax <= 32767) {
+        std::map<int, int> coef;  // 16-bit tile offset -> integer coefficient
+        static const int sign[4] = {1, -1, -1, 1};
+        for (int j = 0; j < d.nrect; j++) {
+          const int32_t* r = &m.haar_rects[(size_t)fi * 12 + j * 4];
+          const int o4[4] = {G16.at(r[1], r[0]), G16.at(r[1], r[0] + r[2]), G16.at(r[1] + r[3], r[0]), G16.at(r[1] + r[3], r[0] + r[2])};
+          for (int k = 0; k < 4; k++) coef[o4[k]] += sign[k] * (int)d.w[j];
+        }
+        std::map<int, std::vector<int>> by_coef;
+        for (auto& kv : coef)
+          if (kv.second) by_coef[std::abs(kv.second)].push_back(kv.second > 0 ? kv.first + 1 : -(kv.first + 1));
+        std::string tt;
+        for (auto& g : by_coef) {
+          std::string grp;
+          for (int so : g.second) {
+            grp += so > 0 ? (grp.empty() ? "" : " + ") : " - ";
+            grp += var_of(std::abs(so) - 1);
+          }
+          if (grp.rfind(" - ", 0) == 0) grp = "0u" + grp;
+          snprintf(buf, sizeof(buf), "%s%du * (", tt.empty() ? "" : " + ", g.first);
+          tt += buf + grp + ")";
+        }
+        if (tt.empty()) tt = "0u";
+        e += "(float)(int)(short)(" + tt + ")";
+      } else {
+        std::string terms_int, terms_float;
+        for (int j = 0; j < d.nrect; j++) {
+          const int32_t* r = &m.haar_rects[(size_t)fi * 12 + j * 4];
+          std::string rj;
+          for (const auto& pc : pieces16(r[0], r[1], r[2], r[3])) {
+            const std::string a = var_of(G16.at(pc[1], pc[0])), b2 = var_of(G16.at(pc[1], pc[0] + pc[2])), c = var_of(G16.at(pc[1] + pc[3], pc[0])),
+                              dd = var_of(G16.at(pc[1] + pc[3], pc[0] + pc[2]));
+            rj += std::string(rj.empty() ? "" : " + ") + "((" + a + " - " + b2 + " - " + c + " + " + dd + ") & 0xffffu)";
+          }
+          if (rj.empty()) rj = "0u";
+          snprintf(buf, sizeof(buf), "%s%d * (int)(", j ? " + " : "", (int)d.w[j]);
+          terms_int += buf + rj + ")";
+          terms_float += std::string(j ? " + " : "") + hexf(d.w[j]) + " * (float)(int)(" + rj + ")";
+        }
+        e += int_ok ? "(float)(" + terms_int + ")" : terms_float;
+      }
+    } else if (int_ok) {
       std::map<int, int> coef;  // LDS offset -> integer coefficient
       static const int sign[4] = {1, -1, -1, 1};
       for (int j = 0; j < d.nrect; j++)
@@ -1089,7 +1225,7 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
         std::string dup;
         int k = 0;
         for (auto& kv : var) {
-          snprintf(buf, sizeof(buf), "{ unsigned dz%d = (unsigned)b%s[%d]; asm volatile(\"\" :: \"v\"(dz%d)); } ", k, win.c_str(), kv.first ^ 1, k);
+          snprintf(buf, sizeof(buf), "{ unsigned dz%d = (unsigned)%s[%d]; asm volatile(\"\" :: \"v\"(dz%d)); } ", k, tile_ptr.c_str(), kv.first ^ 1, k);
           dup += buf;
           k++;
         }
@@ -1122,7 +1258,19 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
       // every vote: integer adds are associative, and without it the compiler re-associates the chain of votes into a
       // tree of partial sums that it then has to spill.
       snprintf(delta, sizeof(delta), "0x%08x", (unsigned)(lq - rq));
-      char vote[256];
+      char vote[512];
+      if (!std::getenv("CCAMD_SPEC_NO_CMPX")) {
+        // The vote as TWO vector instructions: v_cmpx narrows EXEC to the lanes with v < thr (threshold as a 32-bit
+        // literal operand), the delta is added under that mask (again a literal operand), and a scalar move puts EXEC back.
+        // The plain form below costs four (move of the delta into a register, compare, select, add) plus a scalar move of
+        // the threshold. `thr > v` is the comparison `v < thr` with the operands swapped: false for NaN either way.
+        unsigned thr_bits;
+        std::memcpy(&thr_bits, &d.thr, 4);
+        snprintf(vote, sizeof(vote),
+                 "; v *= vnf%s; { unsigned long long sx; asm volatile(\"s_mov_b64 %%1, exec\\n\\tv_cmpx_gt_f32_e32 0x%08x, %%2\\n\\tv_add_u32_e32 %%0, %s, %%0\\n\\ts_mov_b64 exec, %%1\" "
+                 ": \"+v\"(ai%s), \"=&s\"(sx) : \"v\"(v) : \"vcc\"); } }",
+                 win.c_str(), thr_bits, delta, win.c_str());
+      } else
       snprintf(vote, sizeof(vote), "; v *= vnf%s; { unsigned dq; asm volatile(\"v_mov_b32_e32 %%0, %s\" : \"=v\"(dq)); ai%s += (v < %s ? dq : 0u); asm volatile(\"\" : \"+v\"(ai%s)); } }",
                win.c_str(), delta, win.c_str(), hexf(d.thr).c_str(), win.c_str());
       out.compute += e + vote;
@@ -1139,8 +1287,10 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
   };
   for (int step = 1; step <= 2; step++) {
     snprintf(buf, sizeof(buf),
-             "template <>\n__device__ __forceinline__ double spec_stage<%d>(int st, int p_lo, int p_hi, const int32_t* b, float vnf) {\n", step);
+             "template <>\n__device__ %s double spec_stage<%d>(int st, int p_lo, int p_hi, const int32_t* b, float vnf) {\n", spec_stage_inline_attr(), step);
     o += buf;
+    const bool h16 = tile16 && step == 2;  // STEP-2 tiles hold 16-bit entries
+    if (h16) o += "  const unsigned short* h = reinterpret_cast<const unsigned short*>(b);\n";
     o += "  double acc = 0.;\n  switch (st) {\n";
     for (int s = 0; s < n_stages; s++) {
       snprintf(buf, sizeof(buf), "    case %d: {\n", s);
@@ -1149,7 +1299,7 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
       double q = 0.;
       const bool fixed = delta_form && fixed_point_ok && stage_quantum(s, q);
       for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++)
-        st.push_back(stump(t[step - 1][(size_t)m.stage_first[(size_t)s] + i], m.stage_first[(size_t)s] + i, i, "", fixed ? q : 0.));
+        st.push_back(stump(t[step - 1][(size_t)m.stage_first[(size_t)s] + i], m.stage_first[(size_t)s] + i, i, "", fixed ? q : 0., h16));
       if (fixed) {
         o += "      unsigned ai = 0u;\n";
         spec_emit_stage(o, st, depth, true, {"ai"}, true);
@@ -1166,13 +1316,15 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
              "acc_a, double& acc_b) {\n  double acca = 0., accb = 0.;\n  {\n",
              step);
     o += buf;
+    if (h16)
+      o += "  const unsigned short* ha = reinterpret_cast<const unsigned short*>(ba);\n  const unsigned short* hb = reinterpret_cast<const unsigned short*>(bb);\n";
     {
       std::vector<SpecStump> st;
       double q = 0.;
       const bool fixed = delta_form && fixed_point_ok && stage_quantum(0, q);
       for (int i = 0; i < m.stage_ntrees[0]; i++) {
         const HaarStumpDev& d = t[step - 1][(size_t)m.stage_first[0] + i];
-        SpecStump a = stump(d, m.stage_first[0] + i, i, "a", fixed ? q : 0.), b2 = stump(d, m.stage_first[0] + i, i, "b", fixed ? q : 0.);
+        SpecStump a = stump(d, m.stage_first[0] + i, i, "a", fixed ? q : 0., h16), b2 = stump(d, m.stage_first[0] + i, i, "b", fixed ? q : 0., h16);
         st.push_back(SpecStump{a.loads + b2.loads, a.decls + " " + b2.decls, a.compute + " " + b2.compute, a.base, a.base_q});
       }
       if (fixed) {
@@ -1190,10 +1342,13 @@ static std::string spec_stage_source(const Cascade& m, int n_stages) {
 
 // LBP variant: the 16 lattice offsets are immediates; the 256-bit subsets stay a (module-resident) table because the word
 // a lane needs depends on its own code. Integer arithmetic throughout, the expression of stump_vote().
-static std::string spec_stage_source_lbp(const Cascade& m, int n_stages) {
+static std::string spec_stage_source_lbp(const Cascade& m, int n_stages, bool tile16) {
   std::vector<LbpStumpDev> t[2];
   build_lbp_stumps<1>(m, t[0]);
-  build_lbp_stumps<2>(m, t[1]);
+  if (tile16)
+    build_lbp_stumps16(m, t[1]);
+  else
+    build_lbp_stumps<2>(m, t[1]);
   n_stages = std::min<int>(n_stages, (int)m.stage_ntrees.size());
   const int depth = std::min(spec_prefetch_depth(0), 2);  // 16 independent words per stump already: no explicit pipelining measured best (7.8 ms per 32 frames; one stump ahead 8.2, two 8.9)
   std::string o;
@@ -1213,18 +1368,22 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages) {
     snprintf(b2, sizeof(b2), "%af", (double)v);
     return std::string(b2);
   };
-  auto stump = [&](const LbpStumpDev& d, int index, int local, const std::string& win) {
+  auto stump = [&](const LbpStumpDev& d, int index, int local, const std::string& win, bool h16) {
     SpecStump out;
     std::string P[16];
     for (int k = 0; k < 16; k++) {
       snprintf(buf, sizeof(buf), "p%d_%d%s", local, k, win.c_str());
       P[k] = buf;
       out.decls += (k ? ", " : "int ") + P[k];
-      snprintf(buf, sizeof(buf), "%s = b%s[%d]; ", P[k].c_str(), win.c_str(), d.ofs[k]);
+      snprintf(buf, sizeof(buf), "%s = %s%s[%d]; ", P[k].c_str(), h16 ? "h" : "b", win.c_str(), d.ofs[k]);
       out.loads += buf;
     }
     out.decls += ";";
-    auto cell = [&](int a, int b2, int c, int dd) { return P[a] + " - " + P[b2] + " - " + P[c] + " + " + P[dd]; };
+    // 16-bit tile: a cell sum is the low half of the corner combination (exact: 255 * cell area < 2^16, tile16_eligible)
+    auto cell = [&](int a, int b2, int c, int dd) {
+      const std::string v = P[a] + " - " + P[b2] + " - " + P[c] + " + " + P[dd];
+      return h16 ? "((" + v + ") & 0xffff)" : v;
+    };
     std::string e = "{ const int c = " + cell(5, 6, 9, 10) + "; const int lbp = (" + cell(0, 1, 4, 5) + " >= c ? 128 : 0) | (" + cell(1, 2, 5, 6) +
                     " >= c ? 64 : 0) | (" + cell(2, 3, 6, 7) + " >= c ? 32 : 0) | (" + cell(6, 7, 10, 11) + " >= c ? 16 : 0) | (" +
                     cell(10, 11, 14, 15) + " >= c ? 8 : 0) | (" + cell(9, 10, 13, 14) + " >= c ? 4 : 0) | (" + cell(8, 9, 12, 13) +
@@ -1236,8 +1395,10 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages) {
   };
   for (int step = 1; step <= 2; step++) {
     snprintf(buf, sizeof(buf),
-             "template <>\n__device__ __forceinline__ double spec_stage<%d>(int st, int p_lo, int p_hi, const int32_t* b, float vnf) {\n", step);
+             "template <>\n__device__ %s double spec_stage<%d>(int st, int p_lo, int p_hi, const int32_t* b, float vnf) {\n", spec_stage_inline_attr(), step);
     o += buf;
+    const bool h16 = tile16 && step == 2;  // STEP-2 tiles hold 16-bit entries
+    if (h16) o += "  const unsigned short* h = reinterpret_cast<const unsigned short*>(b);\n";
     o += "  double acc = 0.;\n  switch (st) {\n";
     for (int s = 0; s < n_stages; s++) {
       snprintf(buf, sizeof(buf), "    case %d: {\n", s);
@@ -1245,7 +1406,7 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages) {
       std::vector<SpecStump> st;
       for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++) {
         const int idx = m.stage_first[(size_t)s] + i;
-        st.push_back(stump(t[step - 1][(size_t)idx], idx, i, ""));
+        st.push_back(stump(t[step - 1][(size_t)idx], idx, i, "", h16));
       }
       spec_emit_stage(o, st, depth, true, {"acc"});
       o += "    } break;\n";
@@ -1256,11 +1417,13 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages) {
              "acc_a, double& acc_b) {\n  double acca = 0., accb = 0.;\n  {\n",
              step);
     o += buf;
+    if (h16)
+      o += "  const unsigned short* ha = reinterpret_cast<const unsigned short*>(ba);\n  const unsigned short* hb = reinterpret_cast<const unsigned short*>(bb);\n";
     {
       std::vector<SpecStump> st;
       for (int i = 0; i < m.stage_ntrees[0]; i++) {
         const int idx = m.stage_first[0] + i;
-        SpecStump a = stump(t[step - 1][(size_t)idx], idx, i, "a"), b2 = stump(t[step - 1][(size_t)idx], idx, i, "b");
+        SpecStump a = stump(t[step - 1][(size_t)idx], idx, i, "a", h16), b2 = stump(t[step - 1][(size_t)idx], idx, i, "b", h16);
         st.push_back(SpecStump{a.loads + b2.loads, a.decls + " " + b2.decls, a.compute + " " + b2.compute});
       }
       spec_emit_stage(o, st, std::min(depth, 1), false, {"acca", "accb"});
@@ -1389,20 +1552,29 @@ static void build_lbp_nodes(const Cascade& m, std::vector<LbpNodeDev>& out) {
   }
 }
 
-template <int STEP>
-static void build_lbp_stumps(const Cascade& m, std::vector<LbpStumpDev>& out) {
-  const TileGeom<STEP> G(m.win_w, m.win_h);
+template <class At>
+static void build_lbp_stumps_at(const Cascade& m, std::vector<LbpStumpDev>& out, At at) {
   out.resize(m.stump_feature.size());
   for (size_t i = 0; i < out.size(); i++) {
     LbpStumpDev& d = out[i];
     std::memset(&d, 0, sizeof(d));
     const int32_t* r = &m.lbp_rects[(size_t)m.stump_feature[i] * 4];
     for (int rr = 0; rr < 4; rr++)
-      for (int cc = 0; cc < 4; cc++) d.ofs[4 * rr + cc] = G.at(r[1] + rr * r[3], r[0] + cc * r[2]);
+      for (int cc = 0; cc < 4; cc++) d.ofs[4 * rr + cc] = at(r[1] + rr * r[3], r[0] + cc * r[2]);
     d.left = m.stump_left[i];
     d.right = m.stump_right[i];
     for (int j = 0; j < 8; j++) d.subset[j] = m.node_subset[i * 8 + j];
   }
+}
+template <int STEP>
+static void build_lbp_stumps(const Cascade& m, std::vector<LbpStumpDev>& out) {
+  const TileGeom<STEP> G(m.win_w, m.win_h);
+  build_lbp_stumps_at(m, out, [&](int y, int x) { return G.at(y, x); });
+}
+static void build_lbp_gstumps(const Cascade& m, std::vector<LbpStumpDev>& out) { build_lbp_stumps_at(m, out, window_xy); }
+static void build_lbp_stumps16(const Cascade& m, std::vector<LbpStumpDev>& out) {  // STEP-2 tile with 16-bit entries
+  const TileGeom16 G(m.win_w, m.win_h);
+  build_lbp_stumps_at(m, out, [&](int y, int x) { return G.at(y, x); });
 }
 
 static bool same_params(const cc_detect_params& a, const cc_detect_params& b) {
@@ -1642,6 +1814,8 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.nstages = (int)d->m.stage_ntrees.size();
     A.stage_first = d->d_stage_first.p;
     A.stage_ntrees = d->d_stage_ntrees.p;
+    A.group_first = d->d_group_first.p;
+    A.ngroups = d->n_groups;
     A.wave_below = d->wave_below;
     A.stop_after = d->stop_after;
     A.split_stumps = d->split_stumps;
@@ -1666,6 +1840,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.stumps2 = haar ? (const void*)d->d_haar2.p : (const void*)d->d_lbp2.p;
     A.wstumps1 = d->d_haar1w.p ? (const void*)d->d_haar1w.p : A.stumps1;
     A.wstumps2 = d->d_haar2w.p ? (const void*)d->d_haar2w.p : A.stumps2;
+    A.gstumps = haar ? (const void*)d->d_haar_g.p : (const void*)d->d_lbp_g.p;
     A.trees = d->m.max_nodes_per_tree > 1 ? 1 : 0;
     A.nodes1 = haar ? (const void*)d->d_hnode1.p : (const void*)d->d_lnode1.p;
     A.nodes2 = haar ? (const void*)d->d_hnode2.p : (const void*)d->d_lnode2.p;
@@ -1675,7 +1850,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     if (P->n_tiles) {
       if (d->spec_fn && !A.trees) {
         void* params[] = {&A};
-        CC_HIP(hipModuleLaunchKernel(d->spec_fn, (unsigned)P->n_tiles, (unsigned)nf, 1, EVAL_THREADS, 1, 1, (unsigned)d->lds, st, params, nullptr));
+        CC_HIP(hipModuleLaunchKernel(d->spec_fn, (unsigned)P->n_tiles, (unsigned)nf, 1, EVAL_THREADS, 1, 1, (unsigned)d->lds_spec, st, params, nullptr));
       } else if (haar)
         hipLaunchKernelGGL(k_eval_haar, dim3(P->n_tiles, nf), dim3(EVAL_THREADS), d->lds, st, A);
       else
@@ -2033,7 +2208,7 @@ static const char kSpecPrelude[] =
     "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
 
 // Compiles `src` for `arch`; identical (source, options) pairs are served from a per-process cache.
-static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, bool lbp, int win_w, int win_h, std::vector<char>& code) {
+static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, bool lbp, bool tile16, int win_w, int win_h, std::vector<char>& code) {
   static std::mutex mu;
   static std::map<std::string, std::vector<char>> cache;
   const std::string o_arch = "--offload-arch=" + arch, o_k = "-DCC_SPEC_STAGES=" + std::to_string(n_stages);
@@ -2042,8 +2217,11 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
   std::string o_w = "-DCC_EVAL_MIN_WAVES_PER_EU=" + std::to_string(CC_EVAL_MIN_WAVES_PER_EU);
   if (const char* e = std::getenv("CCAMD_SPEC_WAVES_PER_EU")) o_w = "-DCC_EVAL_MIN_WAVES_PER_EU=" + std::to_string(std::max(1, std::min(8, std::atoi(e))));  // tuning
   const std::string o_w0 = "-DCC_SPEC_W0=" + std::to_string(win_w), o_h0 = "-DCC_SPEC_H0=" + std::to_string(win_h);  // tile geometry folds to constants
-  const char* opts[] = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str(), o_w.c_str(), o_w0.c_str(), o_h0.c_str(), "-DCC_SPEC_LBP"};
-  const int n_opts = (int)(sizeof(opts) / sizeof(opts[0])) - (lbp ? 0 : 1);
+  std::vector<const char*> optv = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str(), o_w.c_str(), o_w0.c_str(), o_h0.c_str()};
+  if (lbp) optv.push_back("-DCC_SPEC_LBP");
+  if (tile16) optv.push_back("-DCC_SPEC_TILE16");
+  const char* const* opts = optv.data();
+  const int n_opts = (int)optv.size();
   std::string key;  // everything the code object depends on: compiler version, options, then the source
   {
     int major = 0, minor = 0;
@@ -2137,7 +2315,7 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
   void* prog = nullptr;
   if (rtc.create(&prog, src.c_str(), "cc_eval_kernel_spec.hip", 0, nullptr, nullptr) != 0)
     return set_error(CC_ERR_HIP, "cc_detector_specialize: hiprtcCreateProgram failed");
-  const int rc = rtc.compile(prog, n_opts, opts);
+  const int rc = rtc.compile(prog, n_opts, const_cast<const char**>(opts));
   if (rc != 0) {
     size_t n = 0;
     rtc.log_size(prog, &n);
@@ -2167,7 +2345,7 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
 
 // Host half of the specialisation: source for the first stages (whole stages within the code-size budget) compiled for
 // `arch`. No device calls: safe on a background thread.
-static cc_status spec_build(const Cascade& m, int n_stages, const std::string& arch, std::vector<char>& code, int& k_out) {
+static cc_status spec_build(const Cascade& m, int n_stages, const std::string& arch, std::vector<char>& code, int& k_out, bool& tile16_out) {
   if (m.max_nodes_per_tree > 1) return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: stump cascades only");
   int k = 0, stumps = 0;
   int budget = 320;  // instruction cache: more stages measured no faster, 12 stages slower
@@ -2181,13 +2359,15 @@ static cc_status spec_build(const Cascade& m, int n_stages, const std::string& a
   const std::string marker = "//@@CC_SPEC_FUNCTIONS@@";
   const size_t pos = src.find(marker);
   if (pos == std::string::npos) return set_error(CC_ERR_HIP, "cc_detector_specialize: kernel source has no specialisation marker");
-  src.replace(pos, marker.size(), spec_stage_source(m, k));
+  const bool tile16 = tile16_eligible(m, k);
+  src.replace(pos, marker.size(), spec_stage_source(m, k, tile16));
   k_out = k;
-  return compile_specialised(src, arch, k, m.feature_type == CC_FEATURE_LBP, m.win_w, m.win_h, code);
+  tile16_out = tile16;
+  return compile_specialised(src, arch, k, m.feature_type == CC_FEATURE_LBP, tile16, m.win_w, m.win_h, code);
 }
 
 // Device half: load the code object and make it the detector's cascade kernel. Owning thread only.
-static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int k) {
+static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int k, bool tile16) {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   CC_HIP(hipModuleLoadData(&mod, code.data()));
@@ -2195,8 +2375,14 @@ static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int
     (void)hipModuleUnload(mod);
     return set_error(CC_ERR_HIP, "cc_detector_specialize: entry point not found in the compiled module");
   }
-  if (d->lds > 64 * 1024) {  // same opt-in as the ahead-of-time kernels (cc_detector_create)
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds);
+  size_t lds_spec = d->lds;
+  if (tile16) {  // STEP-1 tile in 32 bits, STEP-2 tile in 16 bits
+    const TileGeom<1> G1(d->m.win_w, d->m.win_h);
+    const TileGeom16 G2(d->m.win_w, d->m.win_h);
+    lds_spec = eval_lds_bytes(std::max(G1.words(), G2.words()), false) + d->lds_extra;
+  }
+  if (lds_spec > 64 * 1024) {  // same opt-in as the ahead-of-time kernels (cc_detector_create)
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec);
     if (e != hipSuccess) {
       (void)hipGetLastError();
       (void)hipModuleUnload(mod);
@@ -2209,6 +2395,8 @@ static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int
   d->spec_mod = mod;
   d->spec_fn = fn;
   d->spec_stages = k;
+  d->lds_spec = lds_spec;
+  d->spec_tile16 = tile16 ? 1 : 0;
   return CC_OK;
 }
 
@@ -2225,7 +2413,7 @@ static void spec_poll(cc_detector* d) {
   const int st = d->spec_bg_state.load(std::memory_order_acquire);
   if (st != 2 && st != 3) return;
   if (d->spec_thread.joinable()) d->spec_thread.join();
-  if (st == 2 && spec_install(d, d->spec_bg_code, d->spec_bg_stages) != CC_OK) d->spec_bg_error = cc_last_error();
+  if (st == 2 && spec_install(d, d->spec_bg_code, d->spec_bg_stages, d->spec_bg_tile16) != CC_OK) d->spec_bg_error = cc_last_error();
   d->spec_bg_code.clear();
   d->spec_bg_state.store(0, std::memory_order_release);
 }
@@ -2242,10 +2430,12 @@ static cc_status spec_start_background(cc_detector* d, int n_stages) {
   d->spec_thread = std::thread([d, n_stages, arch]() {
     std::vector<char> code;
     int k = 0;
-    const cc_status s2 = spec_build(d->m, n_stages, arch, code, k);
+    bool t16 = false;
+    const cc_status s2 = spec_build(d->m, n_stages, arch, code, k, t16);
     if (s2 == CC_OK) {
       d->spec_bg_code.swap(code);
       d->spec_bg_stages = k;
+      d->spec_bg_tile16 = t16;
       d->spec_bg_state.store(2, std::memory_order_release);
     } else {
       d->spec_bg_error = cc_last_error();  // this thread's message
@@ -2312,13 +2502,40 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   if (const char* e = std::getenv("CCAMD_CAND_CAP")) d->cand_cap = std::max(16, std::atoi(e));  // initial candidate-list capacity (tests: forces the overflow path)
   d->even_passes = std::getenv("CCAMD_EVEN_PASSES") ? 1 : 0;
   if (const char* e = std::getenv("CCAMD_DEBUG_EXTRA_LDS")) {  // occupancy experiments: pad the per-block LDS request
-    d->lds += (size_t)std::max(0, std::atoi(e));
+    d->lds_extra = (size_t)std::max(0, std::atoi(e));
+    d->lds += d->lds_extra;
     if (d->lds > 64 * 1024)
       CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(haar ? &k_eval_haar : &k_eval_lbp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds));
   }
   if (const char* e = std::getenv("CCAMD_WAVE_BELOW"))  // tuning knob; only honoured when the reduction is exact
     if (d->wave_below) d->wave_below = std::max(0, std::min(64, std::atoi(e)));  // the wave phase holds one window per lane
   CC_HIP(d->d_stage_thr.upload(d->m.stage_threshold, d->stream));
+  {
+    // Stage groups (EvalArgs::group_first). Every stage boundary inside the cascade kernel costs the block a barrier, the
+    // class counts and a queue rebuild -- about as much as a pass over 25 stumps -- while what it buys is that the windows
+    // rejected by the stage stop occupying lanes. For short stages (the stock LBP cascade has 3-10 stumps per stage) the
+    // boundary costs more than it saves, so consecutive stages are put into one group while the group stays within
+    // `budget` stumps; a stage longer than the budget is a group of its own (the form every stage had before). Grouping
+    // never changes a result: a window's exit stage and stage sum are recorded where it fails, whatever the lanes around
+    // it do. Cascades with deeper trees keep one stage per group.
+    int budget = 0;  // measured (round 3): grouping the stock LBP cascade's stages is slower at every budget, see DESIGN.md
+    if (const char* e = std::getenv("CCAMD_GROUP_STUMPS")) budget = trees ? 0 : std::max(0, std::atoi(e));  // tuning
+    const int dense_budget = 0;  // group 0 = stage 0 alone: the dense phase evaluates exactly one stage
+    std::vector<int> gf;
+    const int nst = (int)d->m.stage_ntrees.size();
+    for (int s0 = 0; s0 < nst;) {
+      gf.push_back(s0);
+      const int cap = s0 == 0 ? dense_budget : budget;
+      int s1 = s0 + 1, sum = d->m.stage_ntrees[(size_t)s0];
+      while (s1 < nst && sum + d->m.stage_ntrees[(size_t)s1] <= cap) sum += d->m.stage_ntrees[(size_t)s1++];
+      s0 = s1;
+    }
+    gf.push_back(nst);
+    if (gf.size() < 2) gf.push_back(nst);  // no stage at all: one empty group, the kernels read group_first[1]
+    d->n_groups = (int)gf.size() - 1;
+    CC_HIP(d->d_group_first.upload(gf, d->stream));
+    CC_HIP(hipStreamSynchronize(d->stream));
+  }
   if (trees) {
     std::vector<int> root(d->m.tree_first_node.begin(), d->m.tree_first_node.end()), leaf0(d->m.tree_first_leaf.begin(), d->m.tree_first_leaf.end());
     CC_HIP(d->d_tree_root.upload(root, d->stream));
@@ -2345,6 +2562,10 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
     build_haar_stumps<2>(d->m, s2);
     CC_HIP(d->d_haar1.upload(s1, d->stream));
     CC_HIP(d->d_haar2.upload(s2, d->stream));
+    std::vector<HaarStumpDev> sg;
+    if (!d->m.has_tilted) build_haar_gstumps(d->m, sg);
+    CC_HIP(d->d_haar_g.upload(sg, d->stream));
+    CC_HIP(hipStreamSynchronize(d->stream));
     if (d->wave_below > 0 && !std::getenv("CCAMD_NO_WAVE_SCHEDULE")) {
       const std::vector<HaarStumpDev> w1 = schedule_for_wave_phase(d->m, s1), w2 = schedule_for_wave_phase(d->m, s2);
       CC_HIP(d->d_haar1w.upload(w1, d->stream));
@@ -2358,6 +2579,9 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
     build_lbp_stumps<2>(d->m, s2);
     CC_HIP(d->d_lbp1.upload(s1, d->stream));
     CC_HIP(d->d_lbp2.upload(s2, d->stream));
+    std::vector<LbpStumpDev> sg;
+    build_lbp_gstumps(d->m, sg);
+    CC_HIP(d->d_lbp_g.upload(sg, d->stream));
     CC_HIP(hipStreamSynchronize(d->stream));
   }
   // CCAMD_AUTO_SPECIALIZE=<stages>: build the specialised kernel in the background; detection starts on the table-driven
@@ -2402,9 +2626,10 @@ cc_status cc_detector_specialize(cc_detector* d, int n_stages) {
   if (st != CC_OK) return st;
   std::vector<char> code;
   int k = 0;
-  st = spec_build(d->m, n_stages, arch, code, k);
+  bool t16 = false;
+  st = spec_build(d->m, n_stages, arch, code, k, t16);
   if (st != CC_OK) return st;
-  return spec_install(d, code, k);
+  return spec_install(d, code, k, t16);
 }
 
 cc_status cc_detector_specialize_async(cc_detector* d, int n_stages) {
@@ -2421,7 +2646,8 @@ cc_status cc_cascade_compile_specialized(const cc_cascade* c, int n_stages, cons
   if (!c || !arch || !code_bytes) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_compile_specialized: null argument");
   std::vector<char> code;
   int k = 0;
-  const cc_status st = spec_build(c->m, std::max(1, n_stages), arch, code, k);
+  bool t16 = false;
+  const cc_status st = spec_build(c->m, std::max(1, n_stages), arch, code, k, t16);
   if (st != CC_OK) return st;
   *code_bytes = code.size();
   return CC_OK;

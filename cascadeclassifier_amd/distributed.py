@@ -38,15 +38,30 @@ class Comm:
 
     @classmethod
     def from_torch(cls, device_index: int, group=None):
+        """Collective over `group`. Rank 0 makes the id; the broadcast carries a flag byte in front of it, so that a
+        failure on rank 0 (librccl missing, ...) reaches every rank through the SAME broadcast and all of them raise --
+        a rank 0 that raised before the broadcast would leave the others waiting in it."""
         import torch
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         dev = torch.device("cuda", device_index) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        msg = torch.zeros(1 + 128, dtype=torch.uint8, device=dev)
+        err = None
         if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, src=0, group=group)
-        return cls(device_index, rank, world, bytes(idt.cpu().numpy().tobytes()))
+            try:
+                uid = cls.unique_id()
+                msg[0] = 1
+                msg[1:].copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
+            except Exception as e:  # noqa: BLE001 -- reported below, after the broadcast every rank takes part in
+                err = e
+        dist.broadcast(msg, src=0, group=group)
+        host = msg.cpu().numpy()
+        if int(host[0]) != 1:
+            if err is not None:
+                raise err
+            from . import _lib as L
+            raise L.CascadeError(L.CC_ERR_UNSUPPORTED, "Comm.from_torch: rank 0 could not create the communicator id")
+        return cls(device_index, rank, world, host[1:].tobytes())
 
     def gather_all(self, per_frame: list[np.ndarray]) -> list[np.ndarray]:
         """cc_gather_detections: this rank's per-frame rectangle lists in, every rank's (global frame order) out."""

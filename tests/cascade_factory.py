@@ -38,12 +38,13 @@ def calibration_values(feats, windows):
     return orc.haar_eval_batch(feats, 0, len(feats), s, t, nf, 24, 24)[:, ok]
 
 
-def tilted_stump_cascade(windows, seed=11, stage_sizes=(6, 10, 14, 20)):
-    """Stump cascade whose features are drawn from the ALL catalog with every second one tilted."""
+def tilted_stump_cascade(windows, seed=11, stage_sizes=(6, 10, 14, 20), tilted=True, min_area=16):
+    """Stump cascade whose features are drawn from the ALL catalog with every second one tilted (tilted=False: upright
+    features only, from rectangles of at least min_area pixels)."""
     rng = np.random.default_rng(seed)
     cat = orc.haar_catalog(24, 24, 2)
-    ti = np.nonzero(cat["tilted"] == 1)[0]
-    ui = np.nonzero((cat["tilted"] == 0) & (cat["r"][:, 0, 2] * cat["r"][:, 0, 3] >= 16))[0]
+    ui = np.nonzero((cat["tilted"] == 0) & (cat["r"][:, 0, 2] * cat["r"][:, 0, 3] >= min_area))[0]
+    ti = np.nonzero(cat["tilted"] == 1)[0] if tilted else ui
     n = sum(stage_sizes)
     idx = np.empty(n, np.int64)
     idx[0::2] = rng.choice(ti, len(idx[0::2]), replace=False)
@@ -63,7 +64,7 @@ def tilted_stump_cascade(windows, seed=11, stage_sizes=(6, 10, 14, 20)):
         weaks = [([(0, -1, k + i, thr[k + i])], [a[k + i] * sign[k + i], -a[k + i] * sign[k + i]]) for i in range(nw)]
         stages.append((st, weaks))
         k += nw
-    return haar_xml(feats, stages)
+    return haar_xml(feats, stages, mode="ALL" if tilted else "BASIC")
 
 
 def lbp_xml(rects, stages, W=24, H=24):

@@ -227,6 +227,8 @@ def test_c_abi_comm_two_ranks_on_one_gpu_either_works_or_fails_loudly():
             p.join(timeout=30)
             if p.is_alive():
                 p.kill()
+    # a rank that aborts at exit (round 2: "double free or corruption" inside librccl after an unused id) must fail the test
+    assert [p.exitcode for p in procs] == [0, 0], [p.exitcode for p in procs]
     kinds = {g[1] for g in got}
     assert len(kinds) == 1, got  # both ranks agree
     if kinds == {"ok"}:
@@ -234,3 +236,132 @@ def test_c_abi_comm_two_ranks_on_one_gpu_either_works_or_fails_loudly():
         assert all(g[2] == want for g in got)
     else:
         print("RCCL refused two ranks on one device:", got[0][2])
+
+
+# ---- the C ABI's world > 1 gather, executed: CPU processes over the tcp transport (CCAMD_COMM_TRANSPORT=tcp) --------
+def _tcp_rank(rank, world, n_frames, case, id_q, out_q):
+    """One rank of a cc_comm_* job. The 128 id bytes travel through a multiprocessing queue (any channel will do)."""
+    import ctypes as C
+    os.environ["CCAMD_COMM_TRANSPORT"] = "tcp"
+    os.environ["CCAMD_COMM_TIMEOUT_S"] = "60"
+    from cascadeclassifier_amd import _lib as L
+    from cascadeclassifier_amd.distributed import Comm
+    if rank == 0:
+        uid = Comm.unique_id()
+        assert Comm.unique_id() == uid  # an id nobody has used yet is handed out again, not replaced
+        for _ in range(world - 1):
+            id_q.put(uid)
+    else:
+        uid = id_q.get(timeout=60)
+    comm = Comm(0, rank, world, uid)
+    assert (L.lib().cc_comm_rank(comm._c), L.lib().cc_comm_world(comm._c)) == (rank, world)
+    lo, hi = shard_range(n_frames, rank, world)
+    mine = [_fake_detections(f) for f in range(lo, hi)]
+    if case == "empty_rank" and rank == 1:
+        mine = [np.zeros((0, 4), np.int32) for _ in mine]  # frames, but not one rectangle
+    res = {}
+    if case == "bad_args" and rank == world - 1:
+        # one rank calls with decreasing offsets: it still takes part in the header exchange, and EVERY rank returns an error
+        nf, nr = C.c_int(0), C.c_int(0)
+        off = np.array([0, 5, 3], np.int32)
+        rects = np.zeros((5, 4), np.int32)
+        st = L.lib().cc_gather_detections(comm._c, rects.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), 2, None, 0, None, 0,
+                                          C.byref(nf), C.byref(nr))
+        res["status"] = st
+    elif case == "bad_args":
+        try:
+            gather_detections(mine, comm=comm)
+            res["status"] = 0
+        except L.CascadeError as e:
+            res["status"] = e.status
+            res["msg"] = str(e)
+    elif case == "small_on_one" and rank == 0:
+        # rank 0 alone passes buffers that are too small: BUFFER_TOO_SMALL after the collectives, then cc_gather_fetch
+        counts = np.array([len(r) for r in mine], np.int32)
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        rects = np.ascontiguousarray(np.concatenate(mine) if mine else np.zeros((0, 4), np.int32), np.int32)
+        nf, nr = C.c_int(0), C.c_int(0)
+        so = np.empty(2, np.int32)
+        st = L.lib().cc_gather_detections(comm._c, rects.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), len(mine), None, 0,
+                                          so.ctypes.data_as(C.c_void_p), 1, C.byref(nf), C.byref(nr))
+        assert st == L.CC_ERR_BUFFER_TOO_SMALL, st
+        out = np.empty((max(nr.value, 1), 4), np.int32)
+        oo = np.empty(nf.value + 1, np.int32)
+        L.check(L.lib().cc_gather_fetch(comm._c, out.ctypes.data_as(C.c_void_p), len(out), oo.ctypes.data_as(C.c_void_p), nf.value))
+        res["all"] = [out[oo[f]:oo[f + 1]].tolist() for f in range(nf.value)]
+    else:
+        res["all"] = [a.tolist() for a in gather_detections(mine, comm=comm)]
+        if case == "twice":  # the communicator is reusable; a second gather with other data
+            res["again"] = [a.tolist() for a in gather_detections(mine[::-1], comm=comm)]
+    comm.close()
+    out_q.put((rank, res))
+
+
+def _run_tcp_job(world, n_frames, case):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    id_q, out_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_tcp_rank, args=(r, world, n_frames, case, id_q, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = dict(out_q.get(timeout=120) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert [p.exitcode for p in procs] == [0] * world, [p.exitcode for p in procs]
+    return got
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 7), (3, 7), (3, 2), (2, 0)])
+def test_c_abi_gather_world_gt_1_over_the_tcp_transport(world, n_frames):
+    """cc_comm_create / cc_gather_detections with world 2 and 3, run by spawned CPU processes: unequal frame counts
+    (7 over 3, 2 over 3 = a rank without frames), padding to the longest payload, unpacking in rank order."""
+    got = _run_tcp_job(world, n_frames, "plain")
+    want = [_fake_detections(f).tolist() for f in range(n_frames)]
+    assert all(got[r]["all"] == want for r in range(world))
+
+
+def test_c_abi_gather_rank_without_rectangles_and_reuse():
+    got = _run_tcp_job(3, 8, "empty_rank")
+    lo, hi = shard_range(8, 1, 3)
+    want = [([] if lo <= f < hi else _fake_detections(f).tolist()) for f in range(8)]
+    assert all(got[r]["all"] == want for r in range(3))
+    got = _run_tcp_job(2, 5, "twice")
+    want = [_fake_detections(f).tolist() for f in range(5)]
+    spans = [shard_range(5, r, 2) for r in range(2)]
+    again = [_fake_detections(f).tolist() for (lo, hi) in spans for f in reversed(range(lo, hi))]
+    assert all(got[r]["all"] == want and got[r]["again"] == again for r in range(2))
+
+
+def test_c_abi_gather_buffer_too_small_on_one_rank_only():
+    """Rank 0 alone has too little room: it gets CC_ERR_BUFFER_TOO_SMALL only after both collectives (the other ranks
+    complete normally) and reads the kept result with cc_gather_fetch, without communicating again."""
+    got = _run_tcp_job(3, 7, "small_on_one")
+    want = [_fake_detections(f).tolist() for f in range(7)]
+    assert all(got[r]["all"] == want for r in range(3))
+
+
+def test_c_abi_gather_bad_arguments_on_one_rank_fail_everywhere_without_a_hang():
+    """Round-2 advisor finding: a rank whose argument check failed returned before the first all-gather and left its peers
+    blocked in it. Now it contributes an error marker and all ranks return CC_ERR_INVALID_ARG together."""
+    from cascadeclassifier_amd import _lib as L
+    got = _run_tcp_job(3, 6, "bad_args")
+    assert [got[r]["status"] for r in range(3)] == [L.CC_ERR_INVALID_ARG] * 3, got
+    assert "rank 2 reported invalid arguments" in got[0]["msg"]
+
+
+def test_comm_getters_and_transport_mismatch(monkeypatch):
+    import ctypes as C
+
+    from cascadeclassifier_amd import _lib as L
+    assert L.lib().cc_comm_rank(None) == -1 and L.lib().cc_comm_world(None) == -1  # not a status code that looks like a rank
+    monkeypatch.setenv("CCAMD_COMM_TRANSPORT", "tcp")
+    buf = C.create_string_buffer(128)
+    L.check(L.lib().cc_comm_unique_id(buf))
+    monkeypatch.delenv("CCAMD_COMM_TRANSPORT")
+    c = C.c_void_p()
+    # an id of the test transport is refused unless the environment selects that transport
+    assert L.lib().cc_comm_create(0, 1, 2, buf, C.byref(c)) == L.CC_ERR_INVALID_ARG

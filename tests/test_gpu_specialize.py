@@ -82,6 +82,90 @@ def test_specialised_tilted_and_other_windows(tmp_path):
     _same_as_oracle(p, orc.load_cascade_xml(path), frame_natural(333, 127, 6), 1.2)
 
 
+@pytest.mark.parametrize("sizes", [(6, 3, 2, 1), (2, 1, 3, 9, 2), (1, 1, 1)])
+def test_specialised_stages_shorter_than_the_part_count(tmp_path, sizes, monkeypatch):
+    """A generated stage is cut into as many parts as the block has wavefronts; a stage with FEWER stumps than that has
+    empty parts, and a call that starts on an empty part must still issue the first stumps' reads (round-2 advisor
+    finding: the prologue was tied to `p_lo == k` and skipped, so 1-3-stump stages summed never-loaded words). Both the
+    whole-stage call and the stump-split slices are exercised (few survivors => the split path)."""
+    img = frame_natural(320, 240, 3)
+    cal = np.stack([img[y:y + 24, x:x + 24] for y in range(0, 200, 9) for x in range(0, 280, 11)])
+    xml = cf.tilted_stump_cascade(cal, seed=5 + len(sizes), stage_sizes=sizes, tilted=False)
+    path = str(tmp_path / "short.xml")
+    open(path, "w").write(xml)
+    o = orc.load_cascade_xml(path)
+    for split in ("1", "0"):
+        monkeypatch.setenv("CCAMD_SPLIT_STUMPS", split)
+        p = cc.CascadeClassifier(path)
+        assert p.specialize(len(sizes)) == len(sizes)
+        n = _same_as_oracle(p, o, frame_natural(333, 227, 6), 1.2)
+        n += _same_as_oracle(p, o, frame_uniform(200, 150, 8), 1.3)
+        assert n > 0
+
+
+@pytest.mark.parametrize("budget", [(0, 0), (8, 24), (7, 12), (1000, 1000)])
+def test_stage_groups_do_not_change_results(lbp_xml, haar_xml, budget, monkeypatch):
+    """Stage groups (one compaction + barrier per GROUP of short stages, lanes leave by predication inside a group):
+    any cut of the cascade into groups must give the same codes, exit stages, stage sums and rectangles -- table-driven
+    and specialised kernels, LBP and Haar, incl. the whole cascade as one dense group."""
+    monkeypatch.setenv("CCAMD_DENSE_STUMPS", str(budget[0]))
+    monkeypatch.setenv("CCAMD_GROUP_STUMPS", str(budget[1]))
+    img, img2 = frame_natural(640, 360, 11), frame_uniform(300, 200, 12)
+    for xml, k in ((lbp_xml, 20), (haar_xml, 4)):
+        o = orc.load_cascade_xml(xml)
+        p = cc.CascadeClassifier(xml)
+        n = _same_as_oracle(p, o, img, 1.1)  # table-driven
+        assert p.specialize(k) == k
+        n += _same_as_oracle(p, o, img, 1.1)
+        n += _same_as_oracle(p, o, img2, 1.25)
+        assert n > 0
+
+
+def test_noinline_generated_stages_match(lbp_xml, haar_xml, monkeypatch):
+    """CCAMD_SPEC_NOINLINE=1: the generated stages as one real function instead of a copy per call site."""
+    monkeypatch.setenv("CCAMD_SPEC_NOINLINE", "1")
+    monkeypatch.setenv("CCAMD_CACHE_DIR", "")
+    img = frame_natural(640, 360, 11)
+    for xml, k in ((lbp_xml, 20), (haar_xml, 7)):
+        p = cc.CascadeClassifier(xml)
+        assert p.specialize(k) == k
+        assert _same_as_oracle(p, orc.load_cascade_xml(xml), img, 1.1) > 0
+
+
+def test_tile16_kernels_match(lbp_xml, haar_xml, tmp_path, monkeypatch):
+    """CCAMD_SPEC_TILE16=1: STEP-2 tiles hold the low 16 bits of the integral (half the LDS bytes, 7-8 resident blocks
+    per CU). Rectangle sums are exact modulo 2^16 while 255 * area < 2^16; larger rectangles are generated as strips that
+    satisfy the bound, the variance rectangle as two halves, and the table-driven stages read the 32-bit integral from
+    global memory. Everything must stay bit-identical: the stock-profile cascade (partly specialised, so that the
+    global-memory records run too), the stock LBP cascade, and a cascade built ONLY from rectangles of >= 258 pixels
+    (every stump takes the strip form)."""
+    monkeypatch.setenv("CCAMD_SPEC_TILE16", "1")
+    img, img2 = frame_natural(640, 360, 11), frame_uniform(300, 200, 12)
+    for xml, k in ((haar_xml, 7), (haar_xml, 2), (lbp_xml, 20), (lbp_xml, 6)):
+        p = cc.CascadeClassifier(xml)
+        assert p.specialize(k) == k
+        o = orc.load_cascade_xml(xml)
+        n = _same_as_oracle(p, o, img, 1.1) + _same_as_oracle(p, o, img2, 1.25)
+        assert n > 0
+    cal = np.stack([img[y:y + 24, x:x + 24] for y in range(0, 300, 9) for x in range(0, 600, 11)])
+    big = cf.tilted_stump_cascade(cal, seed=17, stage_sizes=(5, 8, 11, 14), tilted=False, min_area=258)
+    path = str(tmp_path / "big.xml")
+    open(path, "w").write(big)
+    o = orc.load_cascade_xml(path)
+    assert (o.haar["r"][:, 0, 2] * o.haar["r"][:, 0, 3]).min() >= 258  # every first rectangle exceeds the 16-bit bound
+    for k in (4, 2):
+        p = cc.CascadeClassifier(path)
+        assert p.specialize(k) == k
+        assert _same_as_oracle(p, o, img, 1.1) + _same_as_oracle(p, o, img2, 1.25) > 0
+    frames = np.stack([frame_natural(480, 270, 20 + i) for i in range(6)])
+    p = cc.CascadeClassifier(haar_xml)
+    p.specialize(7)
+    spec = p.detect_batch(frames, 1.1, 3)
+    p.specialize(0)
+    plain = p.detect_batch(frames, 1.1, 3)
+    assert all(a.shape == b.shape and (a == b).all() for a, b in zip(spec, plain))
+
+
 def test_specialised_lbp_cascade(lbp_xml):
     """The stock LBP cascade (20 stages, 139 stumps) compiled whole: bit-exact like the table-driven kernel."""
     o = orc.load_cascade_xml(lbp_xml)

@@ -227,3 +227,15 @@ def test_disk_cache_of_specialised_code_checks_its_header(haar_xml, tmp_path):
     open(files[0], "wb").write(blob[:40])  # truncated file: ignored as well
     st, size4, _, _ = run()
     assert st == 0 and size4 == size and open(files[0], "rb").read() == blob
+
+
+def test_value_cache_policy_of_the_cpp_adaptor():
+    """ccamd/value_cache_policy.hpp (the hit / miss bookkeeping behind CvFeatureEvaluator::operator()) replayed on the
+    trainer's two access shapes: precalculate's row walk costs one launch per feature and teaches the learned list
+    nothing; a mining walk costs one launch per window once the cascade's features are learned (round-2 advisor finding:
+    the first sample of every row used to be taken for a prediction walk). tests/cpp/test_cache_policy.cpp, no GPU."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cascadeclassifier_amd", "lib", "test_cache_policy")
+    assert os.path.exists(exe), "build first: make -C cascadeclassifier_amd/cpp (or __graft_entry__.build())"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "test_cache_policy OK" in r.stdout, r.stdout + r.stderr

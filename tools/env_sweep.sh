@@ -5,7 +5,7 @@ while read -r line; do
   [ -z "$line" ] && continue
   envs="${line%%--*}"; args=""
   case "$line" in *--*) args="${line#*--}";; esac
-  env CCAMD_CACHE_DIR= $envs python bench.py --steps 3 --warmup 1 --cpu-frames 0 --frames 32 --device-only $args 2>/dev/null | python -c "
+  env CCAMD_CACHE_DIR=/tmp/ccamd_sweep_cache $envs python bench.py --steps 3 --warmup 1 --cpu-frames 0 --frames 32 --device-only $args 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('''$line''', '=> eval_ms/32f', d['kernel_ms_per_step']['eval_ms'], 'spec', d['config']['kernel_specialized_stages'])"
 done

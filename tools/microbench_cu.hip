@@ -86,7 +86,7 @@ __global__ __launch_bounds__(1024) void k_lds(const int* __restrict__ addr, unsi
   for (int k = 0; k < 8; k++) a[k] = addr[k * 64 + lane] * 4;  // byte addresses
   __syncthreads();
   int s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
-  int t0v, t1v, t2v, t3v, t4v, t5v, t6v, t7v;
+  int t0v = 0, t1v = 0, t2v = 0, t3v = 0, t4v = 0, t5v = 0, t6v = 0, t7v = 0;
   long long w0, w1, w2, w3, w4, w5, w6, w7;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int i = 0; i < ITER; i++) {
@@ -104,6 +104,20 @@ __global__ __launch_bounds__(1024) void k_lds(const int* __restrict__ addr, unsi
           : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
           : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
       s0 += (int)w0; s1 += (int)(w0 >> 32); s2 += (int)w1; s3 += (int)(w1 >> 32); s4 += (int)w2; s5 += (int)(w2 >> 32); s6 += (int)w3; s7 += (int)(w3 >> 32);
+    } else if (MODE == 3) {  // 8 x ds_read_u16 at byte address = 2 * (pattern value): the pattern counts 16-bit entries
+      asm volatile(
+          "ds_read_u16 %0, %8\n ds_read_u16 %1, %9\n ds_read_u16 %2, %10\n ds_read_u16 %3, %11\n"
+          "ds_read_u16 %4, %12\n ds_read_u16 %5, %13\n ds_read_u16 %6, %14\n ds_read_u16 %7, %15\n s_waitcnt lgkmcnt(0)\n"
+          : "=&v"(t0v), "=&v"(t1v), "=&v"(t2v), "=&v"(t3v), "=&v"(t4v), "=&v"(t5v), "=&v"(t6v), "=&v"(t7v)
+          : "v"(a[0] >> 1), "v"(a[1] >> 1), "v"(a[2] >> 1), "v"(a[3] >> 1), "v"(a[4] >> 1), "v"(a[5] >> 1), "v"(a[6] >> 1), "v"(a[7] >> 1));
+      s0 += t0v; s1 += t1v; s2 += t2v; s3 += t3v; s4 += t4v; s5 += t5v; s6 += t6v; s7 += t7v;
+    } else if (MODE == 4) {  // 4 x (ds_read_u16_d16 + ds_read_u16_d16_hi): two 16-bit entries into one register
+      asm volatile(
+          "ds_read_u16_d16 %0, %4\n ds_read_u16_d16_hi %0, %5\n ds_read_u16_d16 %1, %6\n ds_read_u16_d16_hi %1, %7\n"
+          "ds_read_u16_d16 %2, %8\n ds_read_u16_d16_hi %2, %9\n ds_read_u16_d16 %3, %10\n ds_read_u16_d16_hi %3, %11\n s_waitcnt lgkmcnt(0)\n"
+          : "+&v"(t0v), "+&v"(t1v), "+&v"(t2v), "+&v"(t3v)
+          : "v"(a[0] >> 1), "v"(a[1] >> 1), "v"(a[2] >> 1), "v"(a[3] >> 1), "v"(a[4] >> 1), "v"(a[5] >> 1), "v"(a[6] >> 1), "v"(a[7] >> 1));
+      s0 += t0v; s1 += t1v; s2 += t2v; s3 += t3v;
     } else {  // 8 x ds_read_b64 (addresses rounded down to 8 bytes by the host)
       asm volatile(
           "ds_read_b64 %0, %8\n ds_read_b64 %1, %9\n ds_read_b64 %2, %10\n ds_read_b64 %3, %11\n"
@@ -179,7 +193,7 @@ int main() {
   mk("all lanes one bank (32*lane)", [](int k, int l) { return k + 32 * l; });
   mk("pairs: 2*lane (b64 natural)", [](int k, int l) { return k * 200 + 2 * l; });
   mk("scattered, banks distinct per half", [](int k, int l) { return ((l * 7 + k * 3) % 32) + 32 * ((l * 13 + k) % 150); });
-  for (int mode = 0; mode < 3; mode++)
+  for (int mode = 0; mode < 5; mode++)
     for (auto& p : pats)
       for (int wps : {1, 4}) {
         std::vector<int> w = p.w;
@@ -191,13 +205,16 @@ int main() {
           if (mode == 0) hipLaunchKernelGGL(k_lds<0>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
           if (mode == 1) hipLaunchKernelGGL(k_lds<1>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
           if (mode == 2) hipLaunchKernelGGL(k_lds<2>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
+          if (mode == 3) hipLaunchKernelGGL(k_lds<3>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
+          if (mode == 4) hipLaunchKernelGGL(k_lds<4>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
         }
         CK(hipDeviceSynchronize());
         const double cyc = median_cycles(d_out, blocks);
         const double n_instr = (double)ITER * (mode == 1 ? 4 : 8) * wps * 4;  // wave-instructions per CU
-        const char* mname[] = {"ds_read_b32", "ds_read2_b32", "ds_read_b64"};
-        printf("LDS %-13s %-32s waves/CU=%2d : %.2f cycles per wave-instruction per CU (%.1f B/clk/CU)\n", mname[mode], p.name, wps * 4,
-               cyc / n_instr, (mode == 0 ? 256.0 : 512.0) / (cyc / n_instr));
+        const char* mname[] = {"ds_read_b32", "ds_read2_b32", "ds_read_b64", "ds_read_u16", "ds_read_u16_d16(+hi)"};
+        const double bytes_per_instr[] = {256.0, 512.0, 512.0, 128.0, 128.0};
+        printf("LDS %-20s %-32s waves/CU=%2d : %.2f cycles per wave-instruction per CU (%.1f B/clk/CU)\n", mname[mode], p.name, wps * 4,
+               cyc / n_instr, bytes_per_instr[mode] / (cyc / n_instr));
       }
   return 0;
 }

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Generates the run-time specialised cascade kernel of a cascade on the CPU (no device needed) and compiles it with hipcc
+# to ISA, printing the kernel's resource usage: the quick look at registers / spills / code size before a GPU run.
+#   tools/spec_isa.sh <cascade.xml> <stages> [out_prefix] [extra -D flags...]
+set -e
+xml=$1; k=$2; out=${3:-/tmp/spec/k}; shift; shift; shift || true
+mkdir -p "$(dirname "$out")"
+here=$(cd "$(dirname "$0")/.." && pwd)
+CCAMD_CACHE_DIR= CCAMD_DUMP_SPEC_SOURCE=$out.raw.hip python3 - "$xml" "$k" <<PY
+import sys, ctypes as C
+sys.path.insert(0, "$here")
+from cascadeclassifier_amd import _lib as L
+c = C.c_void_p(); n = C.c_size_t()
+L.check(L.lib().cc_cascade_load_xml(sys.argv[1].encode(), C.byref(c)))
+L.check(L.lib().cc_cascade_compile_specialized(c, int(sys.argv[2]), b"gfx950", C.byref(n)))
+print("hiprtc code object bytes:", n.value)
+PY
+grep -v '^typedef ' $out.raw.hip > $out.hip
+lbp=""; grep -q '<featureType>LBP' "$xml" && lbp="-DCC_SPEC_LBP"
+W=$(grep -o '<width>[0-9]*' "$xml" | head -1 | grep -o '[0-9]*'); H=$(grep -o '<height>[0-9]*' "$xml" | head -1 | grep -o '[0-9]*')
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -include hip/hip_runtime.h -DCC_SPEC_STAGES=$k \
+  -DCC_TILE_Y=${CC_TILE_Y:-8} -DCC_EVAL_THREADS=${CC_EVAL_THREADS:-256} -DCC_EVAL_MIN_WAVES_PER_EU=${WAVES:-5} -DCC_SPEC_W0=$W -DCC_SPEC_H0=$H $lbp "$@" \
+  --cuda-device-only -S -o $out.s -x hip $out.hip -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "remark|error" | sed 's/.*remark: //' | head -40
