@@ -332,24 +332,24 @@ def main():
     src_sha = kernel_source_sha16()
     traffic = None
     traffic_note = None
-    tfile = os.path.join(ROOT, "profiles", "r02_traffic_k_eval.json")
+    tfile = os.path.join(ROOT, "profiles", "r03_traffic_k_eval.json")
     kernel_name = "k_eval_spec" if spec_stages else ("k_eval_haar" if inf["feature_type"] == 0 else "k_eval_lbp")
     if os.path.exists(tfile) and (W, H) == (1920, 1080) and abs(args.scale_factor - 1.1) < 1e-12:
         tj = json.load(open(tfile))
         if tj.get("kernel_src_sha16") == src_sha and tj.get("kernel") == kernel_name:
             traffic = round(tj["hbm_bytes_per_frame"] * frames_per_launch)
-            traffic_note = {"replayed_from": "profiles/r02_traffic_k_eval.json", "profile_kernel_src_sha16": src_sha,
+            traffic_note = {"replayed_from": "profiles/r03_traffic_k_eval.json", "profile_kernel_src_sha16": src_sha,
                             "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes, FETCH x2 (gfx950), scaled to this run's frames per launch"}
         else:
-            traffic_note = {"refused": "profiles/r02_traffic_k_eval.json was measured on other kernel sources or another kernel "
+            traffic_note = {"refused": "profiles/r03_traffic_k_eval.json was measured on other kernel sources or another kernel "
                                        f"({tj.get('kernel')}, {tj.get('kernel_src_sha16')} vs {kernel_name}, {src_sha}): re-run tools/profile_bench.sh"}
     secondary = None
-    pfile = os.path.join(ROOT, "profiles", "r02_pmc_eval.json")
+    pfile = os.path.join(ROOT, "profiles", "r03_pmc_eval.json")
     if os.path.exists(pfile) and (W, H) == (1920, 1080):
         pj = json.load(open(pfile))
         if pj.get("kernel_src_sha16") == src_sha and pj.get("kernel") == kernel_name:
             secondary = {"lds_pipeline_busy": pj["lds_pipeline_busy"], "lds_bank_conflict_share": pj["lds_bank_conflict_share"],
-                         "valu_busy": pj["valu_busy"], "replayed_from": "profiles/r02_pmc_eval.json (tools/pmc_eval.sh)",
+                         "valu_busy": pj["valu_busy"], "valu_active_counter_share": pj.get("valu_active_counter_share"), "replayed_from": "profiles/r03_pmc_eval.json (tools/pmc_eval.sh)",
                          "profile_kernel_src_sha16": src_sha}
     # Secondary limiter measured IN THIS RUN: the rectangle-corner gathers the reference algorithm performs on the windows
     # its scan visits (frame 0: 4 corners of the variance rectangle + 4 per rectangle of every stump the window reaches;

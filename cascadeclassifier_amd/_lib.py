@@ -122,6 +122,7 @@ SIGNATURES = {
     "cc_eval_calc": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
     "cc_eval_calc_list": (_i, [_vp, _vp, _i, _i, _vp]),
     "cc_eval_calc_batch": (_i, [_vp, _i, _i, _vp, _i, _vp, _i]),
+    "cc_eval_calc_batch_device": (_i, [_vp, _i, _i, _vp, _i, _vp, _sz]),
     "cc_eval_calc_batch_sorted": (_i, [_vp, _i, _i, _i, _vp, _vp, _i]),
     "cc_eval_calc_custom_haar": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),
     "cc_haar_feature_calc": (_i, [_i, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),

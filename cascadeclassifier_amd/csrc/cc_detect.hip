@@ -327,52 +327,121 @@ __global__ __launch_bounds__(64) void k_integral_carry(int32_t* __restrict__ hbu
 //   tilted(y, x) = tilted(y-1, x) + p(y-1, x-1) + L(y-1, x-2) + R(y-1, x)
 // (the new bottom pixel of the triangle plus its two new edges), a plain column recurrence; L and R are prefix sums
 // along diagonals: L(y,x) = L(y-1,x-1) + p(y-1,x), R(y,x) = R(y-1,x+1) + p(y-1,x). Pixels outside the image are 0, so
-// every recurrence is border-safe. k_diag_sums: one thread per (anti-)diagonal; k_tilted_cols: one thread per column.
+// every recurrence is border-safe.
+// All three are running sums along y. Round 2 gave a whole diagonal / column to one thread: 1 080 dependent steps for a
+// Full-HD image and only w + h threads per scale. Now the y axis is cut into segments of TSEG rows and each sum runs in
+// two passes, like the band integrals: the *_totals kernels add up a segment (thread = one diagonal or column of one
+// segment), the second kernel starts from the totals of the segments above it (at most h / TSEG small reads) and writes
+// the segment's running sums. ~17x the threads for Full-HD, 64 + 17 dependent steps instead of 1 080.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_diag_sums(const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes, int32_t* __restrict__ diag,
-                                                  size_t int_frame_elems, const ScaleDev* __restrict__ sd, int nscales,
-                                                  const int* __restrict__ blk_first) {
-  const int s = find_segment(blk_first, nscales, blockIdx.x);
+constexpr int TSEG = 64;  // rows per segment
+
+// Layout of the segment totals of one frame, per scale s at tseg_ofs[s]: L totals [nseg][w + h - 1], R totals likewise,
+// then the column totals of the tilted recurrence [nseg][w + 1].
+struct TiltSegs {
+  int nseg, ndiag, ncol;
+  __host__ __device__ TiltSegs(int w, int h) : nseg((h + TSEG - 1) / TSEG), ndiag(w + h - 1), ncol(w + 1) {}
+  __host__ __device__ size_t elems() const { return (size_t)nseg * (2 * (size_t)ndiag + (size_t)ncol); }
+  __host__ __device__ size_t diag_at(int dir, int g) const { return ((size_t)dir * nseg + g) * (size_t)ndiag; }
+  __host__ __device__ size_t col_at(int g) const { return 2 * (size_t)nseg * ndiag + (size_t)g * ncol; }
+};
+
+// A block is TILT_GROUPS wavefronts, each with its own group of 64 adjacent diagonals (or columns). Measured (16 Full-HD
+// frames, rocprofv3): 1 group per block 2.41 ms for the four kernels, 4 groups per block 2.64 ms -- making the 256-byte
+// pieces of neighbouring groups leave one CU together does not help, fewer and fatter blocks schedule worse.
+constexpr int TILT_GROUPS = 1;
+// group = 64 threads = 256 adjacent diagonals of one scale (a thread walks 4 of them: their pixels are 4 consecutive bytes
+// of a row -- one unaligned 32-bit load -- and their sums 4 consecutive words of the output row -- one 16-byte store);
+// blockIdx.y = frame, z = 2 * segment + direction (0: L, x - y constant; 1: R, x + y constant)
+struct __attribute__((packed, aligned(1))) Bytes4 {
+  unsigned d;
+};
+struct __attribute__((packed, aligned(4))) Words4 {
+  int d[4];
+};
+template <bool FINAL>
+__global__ __launch_bounds__(64 * TILT_GROUPS) void k_diag_sums(const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes, int32_t* __restrict__ diag,
+                                                  size_t int_frame_elems, int32_t* __restrict__ tseg, size_t tseg_frame_elems,
+                                                  const long long* __restrict__ tseg_ofs, const ScaleDev* __restrict__ sd, int nscales,
+                                                  const int* __restrict__ blk_first, int n_groups) {
+  const int grp = blockIdx.x * TILT_GROUPS + (threadIdx.x >> 6);
+  if (grp >= n_groups) return;
+  const int s = find_segment(blk_first, nscales, grp);
   const ScaleDev S = sd[s];
-  const int t = (blockIdx.x - blk_first[s]) * 64 + threadIdx.x;
-  if (t >= S.w + S.h - 1) return;
-  const bool anti = blockIdx.z == 1;  // 0: L (x - y constant), 1: R (x + y constant)
+  const TiltSegs T(S.w, S.h);
+  const int t = ((grp - blk_first[s]) * 64 + (threadIdx.x & 63)) * 4;  // first of this thread's 4 diagonals
+  const int dir = blockIdx.z & 1, g = blockIdx.z >> 1;
+  if (t >= T.ndiag || g >= T.nseg) return;
   const uint8_t* img = pyr + (size_t)blockIdx.y * pyr_frame_bytes + S.img_ofs;
-  int32_t* out = diag + ((size_t)blockIdx.y * 2 + blockIdx.z) * int_frame_elems + S.int_ofs;
-  const int d = anti ? t : t - (S.h - 1);
-  int acc = 0;
-  for (int y = 0; y < S.h; y++) {
-    const int x = anti ? d - y : d + y;
-    if (x >= 0 && x < S.w) {
-      acc += img[(size_t)y * S.pitch8 + x];
-      out[(size_t)(y + 1) * S.pitchI + x] = acc;
+  int32_t* tot = tseg + (size_t)blockIdx.y * tseg_frame_elems + tseg_ofs[s];
+  const int d = dir ? t : t - (S.h - 1);
+  const int y0 = g * TSEG, y1 = min(y0 + TSEG, S.h);
+  int acc[4] = {0, 0, 0, 0};
+  if (FINAL)
+    for (int k = 0; k < g; k++)  // the segments above this one
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (t + j < T.ndiag) acc[j] += tot[T.diag_at(dir, k) + t + j];
+  int32_t* out = diag + ((size_t)blockIdx.y * 2 + dir) * int_frame_elems + S.int_ofs;
+  for (int y = y0; y < y1; y++) {
+    const int x = dir ? d - y : d + y;  // column of the first diagonal; the other three follow
+    if (x >= 0 && x + 3 < S.w) {
+      const unsigned px = reinterpret_cast<const Bytes4*>(img + (size_t)y * S.pitch8 + x)->d;
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[j] += (int)((px >> (8 * j)) & 0xffu);
+      if (FINAL) *reinterpret_cast<Words4*>(out + (size_t)(y + 1) * S.pitchI + x) = Words4{{acc[0], acc[1], acc[2], acc[3]}};
+    } else if (x + 3 >= 0 && x < S.w) {  // the image border cuts the group
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (x + j >= 0 && x + j < S.w) {
+          acc[j] += img[(size_t)y * S.pitch8 + x + j];
+          if (FINAL) out[(size_t)(y + 1) * S.pitchI + x + j] = acc[j];
+        }
     }
   }
+  if (!FINAL)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (t + j < T.ndiag) tot[T.diag_at(dir, g) + t + j] = acc[j];
 }
 
-__global__ __launch_bounds__(64) void k_tilted_cols(const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+// group = 64 columns of one scale; blockIdx.y = frame, z = segment (rows y0 + 1 .. y1 of the tilted integral)
+template <bool FINAL>
+__global__ __launch_bounds__(64 * TILT_GROUPS) void k_tilted_cols(const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                     const int32_t* __restrict__ diag, int32_t* __restrict__ integ,
-                                                    size_t int_frame_elems, int nchan, int tilt_chan,
-                                                    const ScaleDev* __restrict__ sd, int nscales, const int* __restrict__ blk_first) {
-  const int s = find_segment(blk_first, nscales, blockIdx.x);
+                                                    size_t int_frame_elems, int nchan, int tilt_chan, int32_t* __restrict__ tseg,
+                                                    size_t tseg_frame_elems, const long long* __restrict__ tseg_ofs,
+                                                    const ScaleDev* __restrict__ sd, int nscales, const int* __restrict__ blk_first,
+                                                    int n_groups) {
+  const int grp = blockIdx.x * TILT_GROUPS + (threadIdx.x >> 6);
+  if (grp >= n_groups) return;
+  const int s = find_segment(blk_first, nscales, grp);
   const ScaleDev S = sd[s];
-  const int x = (blockIdx.x - blk_first[s]) * 64 + threadIdx.x;
-  if (x > S.w) return;
+  const TiltSegs Tg(S.w, S.h);
+  const int x = (grp - blk_first[s]) * 64 + (threadIdx.x & 63);
+  const int g = blockIdx.z;
+  if (x > S.w || g >= Tg.nseg) return;
   const uint8_t* img = pyr + (size_t)blockIdx.y * pyr_frame_bytes + S.img_ofs;
   const int32_t* L = diag + ((size_t)blockIdx.y * 2 + 0) * int_frame_elems + S.int_ofs;
   const int32_t* R = diag + ((size_t)blockIdx.y * 2 + 1) * int_frame_elems + S.int_ofs;
   int32_t* T = integ + ((size_t)blockIdx.y * nchan + tilt_chan) * int_frame_elems + S.int_ofs;
+  int32_t* tot = tseg + (size_t)blockIdx.y * tseg_frame_elems + tseg_ofs[s];
+  const int y0 = g * TSEG + 1, y1 = min(y0 + TSEG - 1, S.h);  // integral rows of this segment
   int acc = 0;
-  T[x] = 0;
-  for (int y = 1; y <= S.h; y++) {
-    int g = x >= 1 ? img[(size_t)(y - 1) * S.pitch8 + (x - 1)] : 0;
-    if (y >= 2) {
-      if (x >= 2) g += L[(size_t)(y - 1) * S.pitchI + (x - 2)];
-      if (x < S.w) g += R[(size_t)(y - 1) * S.pitchI + x];
-    }
-    acc += g;
-    T[(size_t)y * S.pitchI + x] = acc;
+  if (FINAL) {
+    for (int k = 0; k < g; k++) acc += tot[Tg.col_at(k) + x];
+    if (g == 0) T[x] = 0;  // row 0
   }
+  for (int y = y0; y <= y1; y++) {
+    int v = x >= 1 ? img[(size_t)(y - 1) * S.pitch8 + (x - 1)] : 0;
+    if (y >= 2) {
+      if (x >= 2) v += L[(size_t)(y - 1) * S.pitchI + (x - 2)];
+      if (x < S.w) v += R[(size_t)(y - 1) * S.pitchI + x];
+    }
+    acc += v;
+    if (FINAL) T[(size_t)y * S.pitchI + x] = acc;
+  }
+  if (!FINAL) tot[Tg.col_at(g) + x] = acc;
 }
 
 // Calibration stream for the FETCH_SIZE counter: same load shape as stage_tile (dword per lane, coalesced).
@@ -690,6 +759,44 @@ struct DevBuf {
 
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
+// Segment totals of the tilted front end (k_diag_sums / k_tilted_cols): where each scale's totals start, per frame.
+struct TiltPlan {
+  DevBuf<long long> d_ofs;
+  size_t frame_elems = 0;
+  int max_nseg = 0;
+  hipError_t build(const std::vector<ScaleDev>& sd, hipStream_t st) {
+    std::vector<long long> ofs(sd.size() + 1, 0);
+    max_nseg = 0;
+    for (size_t i = 0; i < sd.size(); i++) {
+      const TiltSegs T(sd[i].w, sd[i].h);
+      ofs[i + 1] = ofs[i] + (long long)T.elems();
+      max_nseg = std::max(max_nseg, T.nseg);
+    }
+    frame_elems = (size_t)ofs[sd.size()];
+    hipError_t e = d_ofs.upload(ofs, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // `ofs` goes out of scope
+    return e;
+  }
+};
+
+// Tilted integral of every scale of nf frames into channel tilt_chan of `integ` (diag: 2 x int_frame_elems per frame of
+// scratch for the diagonal sums, tseg: tp.frame_elems per frame for the segment totals).
+static void launch_tilted(hipStream_t st, const TiltPlan& tp, int32_t* tseg, const uint8_t* pyr, size_t pyr_frame_bytes, int32_t* diag,
+                          int32_t* integ, size_t int_frame_elems, int nchan, int tilt_chan, const ScaleDev* sd, int ns,
+                          const int* diag_first, int n_diag_blocks, const int* tcol_first, int n_tcol_blocks, int nf) {
+  if (tp.max_nseg == 0 || nf == 0) return;
+  const dim3 gd((n_diag_blocks + TILT_GROUPS - 1) / TILT_GROUPS, nf, 2 * tp.max_nseg), gc((n_tcol_blocks + TILT_GROUPS - 1) / TILT_GROUPS, nf, tp.max_nseg);
+  const dim3 bt(64 * TILT_GROUPS);
+  hipLaunchKernelGGL(k_diag_sums<false>, gd, bt, 0, st, pyr, pyr_frame_bytes, diag, int_frame_elems, tseg, tp.frame_elems, tp.d_ofs.p, sd, ns,
+                     diag_first, n_diag_blocks);
+  hipLaunchKernelGGL(k_diag_sums<true>, gd, bt, 0, st, pyr, pyr_frame_bytes, diag, int_frame_elems, tseg, tp.frame_elems, tp.d_ofs.p, sd, ns,
+                     diag_first, n_diag_blocks);
+  hipLaunchKernelGGL(k_tilted_cols<false>, gc, bt, 0, st, pyr, pyr_frame_bytes, diag, integ, int_frame_elems, nchan, tilt_chan, tseg,
+                     tp.frame_elems, tp.d_ofs.p, sd, ns, tcol_first, n_tcol_blocks);
+  hipLaunchKernelGGL(k_tilted_cols<true>, gc, bt, 0, st, pyr, pyr_frame_bytes, diag, integ, int_frame_elems, nchan, tilt_chan, tseg,
+                     tp.frame_elems, tp.d_ofs.p, sd, ns, tcol_first, n_tcol_blocks);
+}
+
 struct Plan {
   int w = 0, h = 0;
   cc_detect_params p{};
@@ -704,6 +811,7 @@ struct Plan {
   DevBuf<int> d_resize_first, d_band_first, d_col_first, d_gridrow_first, d_diag_first, d_tcol_first, d_xofs, d_yofs;
   DevBuf<uint16_t> d_xw1, d_yw1;
   DevBuf<int4> d_tiles;
+  TiltPlan tilt;
   // Single-image calls (the detection tool's shape) are launch-bound: ~10 launches, memsets and copies for well under a
   // millisecond of device work. After a first ordinary call has sized every buffer, the whole pass (H2D copy of the
   // image, pyramid, integrals, cascade kernel, skip filter, copy-back of the counters) is captured into a hipGraph and
@@ -758,7 +866,7 @@ struct cc_detector {
   DevBuf<uint8_t> d_frames, d_pyr;
   // The integral images are double-buffered: pyramid + integrals of pass i+1 are built on `front_stream` while the
   // cascade kernel of pass i (LDS/VALU-bound, leaves wave slots and all of HBM idle) runs on `stream`.
-  DevBuf<int32_t> d_integ[2], d_hbuf, d_diag;
+  DevBuf<int32_t> d_integ[2], d_hbuf, d_diag, d_tseg;
   hipStream_t front_stream = nullptr;
   hipEvent_t front_done[2] = {nullptr, nullptr}, eval_done[2] = {nullptr, nullptr}, batch_begin = nullptr;
   bool eval_pending[2] = {false, false};
@@ -823,7 +931,8 @@ struct cc_negminer {
   DevBuf<float> d_stage_thr, d_leaves;
   // per-image workspace
   DevBuf<uint8_t> d_src, d_pyr, d_pass, d_pix;
-  DevBuf<int32_t> d_integ, d_hbuf, d_diag;
+  DevBuf<int32_t> d_integ, d_hbuf, d_diag, d_tseg;
+  TiltPlan tilt;
   DevBuf<ScaleDev> d_sd;
   DevBuf<MineLevel> d_levels;
   DevBuf<int> d_resize_first, d_band_first, d_col_first, d_diag_first, d_tcol_first, d_xofs, d_yofs;
@@ -1033,13 +1142,16 @@ static std::vector<std::array<int, 4>> pieces16(int x, int y, int w, int h) {
 // Can the first n_stages stages be generated for STEP-2 tiles with 16-bit entries (TileGeom16)? Upright Haar features
 // (any rectangle is cut into strips that fit) or LBP cells that fit; the variance rectangle is read as two halves.
 static bool tile16_eligible(const Cascade& m, int n_stages) {
-  // Opt-in (CCAMD_SPEC_TILE16=1): measured in round 3, the 16-bit tile raises the resident blocks per CU from 5 to 7
-  // and the thread-per-window stages gain 4 %, but the table-driven wave phase then reads its corners from global memory
-  // and loses twice that: the kernel as a whole is 15 % slower than with the 32-bit tile.
-  const char* on = std::getenv("CCAMD_SPEC_TILE16");
-  if (!on || std::atoi(on) == 0) return false;
+  // Measured in round 3. Haar: the 16-bit tile raises the resident blocks per CU from 5 to 7 and the
+  // thread-per-window stages gain 4 %, but the table-driven wave phase then reads its corners from global memory and loses
+  // twice that: 15 % slower as a whole -> only on request (CCAMD_SPEC_TILE16=1). LBP with EVERY stage compiled (the stock
+  // cascade: 20 stages, 139 stumps) has no table-driven stage and no wave phase, and its short stages are chains of
+  // dependent stump latencies that more resident wavefronts do hide: 7.6 -> 6.7 ms per 32 frames -> on by default.
   if (m.max_nodes_per_tree > 1) return false;
-  n_stages = std::min<int>(n_stages, (int)m.stage_ntrees.size());
+  const int total = (int)m.stage_ntrees.size();
+  n_stages = std::min<int>(n_stages, total);
+  const char* on = std::getenv("CCAMD_SPEC_TILE16");
+  if (on ? std::atoi(on) == 0 : !(m.feature_type == CC_FEATURE_LBP && n_stages == total)) return false;
   if (m.feature_type == CC_FEATURE_HAAR) {
     if (m.has_tilted) return false;
     const int nrx = m.win_w - 2, nry = m.win_h - 2;
@@ -1355,6 +1467,7 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages, bool ti
   char buf[1024];
   int n_stumps = 0;
   for (int s = 0; s < n_stages; s++) n_stumps += m.stage_ntrees[(size_t)s];
+  const bool lbp_select_words = std::getenv("CCAMD_SPEC_LBP_TABLE") == nullptr;  // tuning: the table form of round 2
   o += "static __device__ const int kSpecSubsets[][8] = {\n";
   for (int i = 0; i < n_stumps; i++) {
     const LbpStumpDev& d = t[0][(size_t)i];
@@ -1388,6 +1501,25 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages, bool ti
                     " >= c ? 64 : 0) | (" + cell(2, 3, 6, 7) + " >= c ? 32 : 0) | (" + cell(6, 7, 10, 11) + " >= c ? 16 : 0) | (" +
                     cell(10, 11, 14, 15) + " >= c ? 8 : 0) | (" + cell(9, 10, 13, 14) + " >= c ? 4 : 0) | (" + cell(8, 9, 12, 13) +
                     " >= c ? 2 : 0) | (" + cell(4, 5, 8, 9) + " >= c ? 1 : 0); ";
+    if (lbp_select_words) {
+      // The 256-bit subset as eight literals picked by the three top bits of the code -- the results of the first three
+      // comparisons -- through seven unconditional selects, instead of a load from a table: the table word depends on the
+      // lane's own code, so it is a vector memory load whose latency sits in every stump's dependency chain, and the late
+      // stages (a handful of windows per tile) are nothing but that chain.
+      const int* w = d.subset;
+      std::string t = "{ const int c = " + cell(5, 6, 9, 10) + "; const bool b7 = " + cell(0, 1, 4, 5) + " >= c, b6 = " + cell(1, 2, 5, 6) +
+                      " >= c, b5 = " + cell(2, 3, 6, 7) + " >= c; const int lo = (" + cell(6, 7, 10, 11) + " >= c ? 16 : 0) | (" +
+                      cell(10, 11, 14, 15) + " >= c ? 8 : 0) | (" + cell(9, 10, 13, 14) + " >= c ? 4 : 0) | (" + cell(8, 9, 12, 13) +
+                      " >= c ? 2 : 0) | (" + cell(4, 5, 8, 9) + " >= c ? 1 : 0); ";
+      snprintf(buf, sizeof(buf),
+               "const unsigned l0 = b5 ? 0x%08xu : 0x%08xu, l1 = b5 ? 0x%08xu : 0x%08xu, l2 = b5 ? 0x%08xu : 0x%08xu, l3 = b5 ? 0x%08xu : 0x%08xu; "
+               "const unsigned m0 = b6 ? l1 : l0, m1 = b6 ? l3 : l2; const unsigned sw = b7 ? m1 : m0; "
+               "acc%s += (double)(((sw >> lo) & 1u) ? %s : %s); }",
+               (unsigned)w[1], (unsigned)w[0], (unsigned)w[3], (unsigned)w[2], (unsigned)w[5], (unsigned)w[4], (unsigned)w[7], (unsigned)w[6],
+               win.c_str(), hexf(d.left).c_str(), hexf(d.right).c_str());
+      out.compute = t + buf;
+      return out;
+    } else
     snprintf(buf, sizeof(buf), "acc%s += (double)((kSpecSubsets[%d][lbp >> 5] & (1 << (lbp & 31))) ? %s : %s); }", win.c_str(), index,
              hexf(d.left).c_str(), hexf(d.right).c_str());
     out.compute = e + buf;
@@ -1638,7 +1770,7 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
     band_first[i + 1] = band_first[i] + S.nbands;
     col_first[i + 1] = col_first[i] + (S.pitchI / 4 + 63) / 64;
     gridrow_first[i + 1] = gridrow_first[i] + g.ny;
-    diag_first[i + 1] = diag_first[i] + (g.w + g.h - 1 + 63) / 64;
+    diag_first[i + 1] = diag_first[i] + (g.w + g.h - 1 + 255) / 256;  // k_diag_sums: a thread walks 4 diagonals
     tcol_first[i + 1] = tcol_first[i] + (g.w + 1 + 63) / 64;
     const int ntx = (g.nx + TILE_X - 1) / TILE_X, nty = (g.ny + TILE_Y - 1) / TILE_Y;
     for (int ty_ = 0; ty_ < nty; ty_++)
@@ -1683,6 +1815,7 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
   CC_HIP(P->d_xw1.upload(xw1, st));
   CC_HIP(P->d_yw1.upload(yw1, st));
   CC_HIP(P->d_tiles.upload(tiles, st));
+  if (d->m.feature_type == CC_FEATURE_HAAR && d->m.has_tilted) CC_HIP(P->tilt.build(P->sd, st));
   CC_HIP(hipStreamSynchronize(st));  // host vectors go out of scope
   *out = P.get();
   if (d->plans.size() >= 8) d->plans.erase(d->plans.begin());
@@ -1767,7 +1900,10 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   CC_HIP(d->d_pyr.ensure(P->pyr_frame_bytes * (size_t)d->pass_capacity));
   CC_HIP(d->d_integ[slot].ensure(P->int_frame_elems * (size_t)nchan * (size_t)d->pass_capacity));
   CC_HIP(d->d_hbuf.ensure(std::max<size_t>(P->h_frame_elems * (size_t)nchan * (size_t)d->pass_capacity, 4)));
-  if (tilt) CC_HIP(d->d_diag.ensure(P->int_frame_elems * 2 * (size_t)d->pass_capacity));
+  if (tilt) {
+    CC_HIP(d->d_diag.ensure(P->int_frame_elems * 2 * (size_t)d->pass_capacity));
+    CC_HIP(d->d_tseg.ensure(std::max<size_t>(P->tilt.frame_elems * (size_t)d->pass_capacity, 1)));
+  }
   CC_HIP(d->d_masks.ensure(std::max<size_t>(P->mask_frame_words * (size_t)d->pass_capacity, 1)));
   if (d->cand_cap == 0) d->cand_cap = 1 << 18;
   CC_HIP(d->d_cands.ensure((size_t)d->cand_cap));
@@ -1791,10 +1927,8 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
                     P->h_frame_elems, P->d_sd.p, ns, P->d_band_first.p, P->n_bands, P->d_col_first.p, P->n_col_blocks, nf,
                     /*sq_odd_rows_only=*/sq_compact);
     if (tilt) {
-      hipLaunchKernelGGL(k_diag_sums, dim3(P->n_diag_blocks, nf, 2), dim3(64), 0, fs, d->d_pyr.p, P->pyr_frame_bytes, d->d_diag.p,
-                         P->int_frame_elems, P->d_sd.p, ns, P->d_diag_first.p);
-      hipLaunchKernelGGL(k_tilted_cols, dim3(P->n_tcol_blocks, nf), dim3(64), 0, fs, d->d_pyr.p, P->pyr_frame_bytes, d->d_diag.p,
-                         d->d_integ[slot].p, P->int_frame_elems, nchan, 2, P->d_sd.p, ns, P->d_tcol_first.p);
+      launch_tilted(fs, P->tilt, d->d_tseg.p, d->d_pyr.p, P->pyr_frame_bytes, d->d_diag.p, d->d_integ[slot].p, P->int_frame_elems, nchan, 2,
+                    P->d_sd.p, ns, P->d_diag_first.p, P->n_diag_blocks, P->d_tcol_first.p, P->n_tcol_blocks, nf);
     }
   }
   if (fs != st) {
@@ -1953,7 +2087,7 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       return CC_OK;
     };
     auto key_now = [&]() {
-      return std::vector<const void*>{d->d_frames.p, d->h_frame, d->d_pyr.p, d->d_integ[0].p, d->d_hbuf.p, d->d_diag.p, d->d_masks.p, d->d_cands.p,
+      return std::vector<const void*>{d->d_frames.p, d->h_frame, d->d_pyr.p, d->d_integ[0].p, d->d_hbuf.p, d->d_diag.p, d->d_tseg.p, d->d_masks.p, d->d_cands.p,
                                       d->d_out[0].p, d->d_counts[0].p, d->h_counts, (const void*)d->spec_fn, (const void*)d->stream,
                                       (const void*)(size_t)d->cand_cap, (const void*)(size_t)d->wave_below, (const void*)(size_t)(d->stop_after + 16)};
     };
@@ -2214,7 +2348,8 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
   const std::string o_arch = "--offload-arch=" + arch, o_k = "-DCC_SPEC_STAGES=" + std::to_string(n_stages);
   const std::string o_ty = "-DCC_TILE_Y=" + std::to_string(TILE_Y), o_th = "-DCC_EVAL_THREADS=" + std::to_string(EVAL_THREADS);
   // same code generation rules as the ahead-of-time build (Makefile): no FMA contraction, no fast-math
-  std::string o_w = "-DCC_EVAL_MIN_WAVES_PER_EU=" + std::to_string(CC_EVAL_MIN_WAVES_PER_EU);
+  // register budget = the occupancy the LDS footprint allows: 5 blocks per CU with the 32-bit tile, 7-8 with the 16-bit one
+  std::string o_w = "-DCC_EVAL_MIN_WAVES_PER_EU=" + std::to_string(tile16 ? 7 : CC_EVAL_MIN_WAVES_PER_EU);
   if (const char* e = std::getenv("CCAMD_SPEC_WAVES_PER_EU")) o_w = "-DCC_EVAL_MIN_WAVES_PER_EU=" + std::to_string(std::max(1, std::min(8, std::atoi(e))));  // tuning
   const std::string o_w0 = "-DCC_SPEC_W0=" + std::to_string(win_w), o_h0 = "-DCC_SPEC_H0=" + std::to_string(win_h);  // tile geometry folds to constants
   std::vector<const char*> optv = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str(), o_w.c_str(), o_w0.c_str(), o_h0.c_str()};
@@ -2518,14 +2653,19 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
     // `budget` stumps; a stage longer than the budget is a group of its own (the form every stage had before). Grouping
     // never changes a result: a window's exit stage and stage sum are recorded where it fails, whatever the lanes around
     // it do. Cascades with deeper trees keep one stage per group.
-    int budget = 0;  // measured (round 3): grouping the stock LBP cascade's stages is slower at every budget, see DESIGN.md
+    // Measured (round 3, stock LBP cascade, ms per 32 Full-HD frames alone on the device; tools/sweeps/r3_*.txt): grouping
+    // from stage 1 on is slower at every budget but 12 stumps (-3 %), because the lanes of windows that died inside a
+    // group keep executing; the gain is in the LATE stages, where a handful of windows per tile pay a barrier round per
+    // stage. Hence two knobs: groups start at stage `from`, and hold up to `budget` stumps.
+    const bool lbp = !haar && !trees;
+    int budget = lbp ? 30 : 0, from = lbp ? 4 : 1;  // LBP: 7.63 -> 7.51 (32-bit tile), 6.72 -> 6.67 (16-bit tile)
     if (const char* e = std::getenv("CCAMD_GROUP_STUMPS")) budget = trees ? 0 : std::max(0, std::atoi(e));  // tuning
-    const int dense_budget = 0;  // group 0 = stage 0 alone: the dense phase evaluates exactly one stage
+    if (const char* e = std::getenv("CCAMD_GROUP_FROM")) from = std::max(1, std::atoi(e));
     std::vector<int> gf;
     const int nst = (int)d->m.stage_ntrees.size();
     for (int s0 = 0; s0 < nst;) {
       gf.push_back(s0);
-      const int cap = s0 == 0 ? dense_budget : budget;
+      const int cap = s0 < from ? 0 : budget;  // stage 0 is the dense phase: always alone
       int s1 = s0 + 1, sum = d->m.stage_ntrees[(size_t)s0];
       while (s1 < nst && sum + d->m.stage_ntrees[(size_t)s1] <= cap) sum += d->m.stage_ntrees[(size_t)s1++];
       s0 = s1;
@@ -2918,16 +3058,18 @@ cc_status cc_integral_u8(int device, const uint8_t* img, int width, int height, 
   if (sqsum) CC_HIP(hipMemcpy2D(sqsum, opitch, d_int.p + elems, (size_t)S.pitchI * 4, opitch, height + 1, hipMemcpyDeviceToHost));
   if (tilted) {  // same kernels as the detection pipeline
     DevBuf<int32_t> d_diag;
-    std::vector<int> diag_first{0, (width + height - 1 + 63) / 64}, tcol_first{0, (width + 1 + 63) / 64};
+    std::vector<int> diag_first{0, (width + height - 1 + 255) / 256}, tcol_first{0, (width + 1 + 63) / 64};
     DevBuf<int> d_diag_first, d_tcol_first;
     CC_HIP(d_diag_first.upload(diag_first, nullptr));
     CC_HIP(d_tcol_first.upload(tcol_first, nullptr));
     CC_HIP(d_diag.ensure(elems * 2));
     CC_HIP(d_tilt.ensure(elems));
-    hipLaunchKernelGGL(k_diag_sums, dim3(diag_first[1], 1, 2), dim3(64), 0, nullptr, d_img.p, (size_t)0, d_diag.p, elems, d_sd.p, 1,
-                       d_diag_first.p);
-    hipLaunchKernelGGL(k_tilted_cols, dim3(tcol_first[1], 1), dim3(64), 0, nullptr, d_img.p, (size_t)0, d_diag.p, d_tilt.p, elems, 1, 0,
-                       d_sd.p, 1, d_tcol_first.p);
+    TiltPlan tp;
+    CC_HIP(tp.build(std::vector<ScaleDev>(1, S), nullptr));
+    DevBuf<int32_t> d_tseg;
+    CC_HIP(d_tseg.ensure(std::max<size_t>(tp.frame_elems, 1)));
+    launch_tilted(nullptr, tp, d_tseg.p, d_img.p, (size_t)0, d_diag.p, d_tilt.p, elems, 1, 0, d_sd.p, 1, d_diag_first.p, diag_first[1],
+                  d_tcol_first.p, tcol_first[1], 1);
     CC_HIP(hipGetLastError());
     CC_HIP(hipMemcpy2D(tilted, opitch, d_tilt.p, (size_t)S.pitchI * 4, opitch, height + 1, hipMemcpyDeviceToHost));
   }
@@ -3113,7 +3255,7 @@ cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int he
     resize_first[i + 1] = resize_first[i] + resize_blocks(S.pitch8, S.h);
     band_first[i + 1] = band_first[i] + S.nbands;
     col_first[i + 1] = col_first[i] + (S.pitchI / 4 + 63) / 64;
-    diag_first[i + 1] = diag_first[i] + (S.w + S.h - 1 + 63) / 64;
+    diag_first[i + 1] = diag_first[i] + (S.w + S.h - 1 + 255) / 256;
     tcol_first[i + 1] = tcol_first[i] + (S.w + 1 + 63) / 64;
   }
   *n_windows = wins;
@@ -3144,10 +3286,10 @@ cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int he
                   band_first[nl], m->d_col_first.p, col_first[nl], 1);
   if (tilt) {
     CC_HIP(m->d_diag.ensure(chan_elems * 2));
-    hipLaunchKernelGGL(k_diag_sums, dim3(diag_first[nl], 1, 2), dim3(64), 0, s, m->d_pyr.p, (size_t)0, m->d_diag.p, chan_elems, m->d_sd.p, nl,
-                       m->d_diag_first.p);
-    hipLaunchKernelGGL(k_tilted_cols, dim3(tcol_first[nl], 1), dim3(64), 0, s, m->d_pyr.p, (size_t)0, m->d_diag.p, m->d_integ.p, chan_elems,
-                       nchan, 2, m->d_sd.p, nl, m->d_tcol_first.p);
+    CC_HIP(m->tilt.build(sd, s));
+    CC_HIP(m->d_tseg.ensure(std::max<size_t>(m->tilt.frame_elems, 1)));
+    launch_tilted(s, m->tilt, m->d_tseg.p, m->d_pyr.p, (size_t)0, m->d_diag.p, m->d_integ.p, chan_elems, nchan, 2, m->d_sd.p, nl,
+                  m->d_diag_first.p, diag_first[nl], m->d_tcol_first.p, tcol_first[nl], 1);
   }
   MineArgs A;
   A.integ = m->d_integ.p;

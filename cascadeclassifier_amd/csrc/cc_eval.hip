@@ -99,7 +99,8 @@ struct BatchArgs {
   int feat_begin, feat_end;   // indices into the feature table
   int feats_per_block;
   const void* feats;
-  float* out;                 // [feat_end - feat_begin][n_samples]
+  float* out;                 // [feat_end - feat_begin][out_pitch], the first n_samples of a row are written
+  size_t out_pitch;           // elements between the rows of two features (>= n_samples)
   int n_tiles, xcd_tiles;     // wide kernel: sample tiles, and whether the grid is laid out XCD by XCD
   int debug_nostore;          // timing experiment: skip the output stores
   int normalized;             // Haar: divide by normfactor (operator()) or not (Feature::calc)
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(BATCH_THREADS) void k_eval_batch(BatchArgs A) {
                   F.w[1] * (float)(at(F.p[1][0]) - at(F.p[1][1]) - at(F.p[1][2]) + at(F.p[1][3]));
       if (F.w[2] != 0.0f) ret += F.w[2] * (float)(at(F.p[2][0]) - at(F.p[2][1]) - at(F.p[2][2]) + at(F.p[2][3]));
       const float val = A.normalized ? (nf == 0.0f ? 0.0f : div_by_refined(ret, nf, y1)) : ret;
-      if (valid && (!A.debug_nostore || val == 12345.678f)) A.out[(size_t)(f - A.feat_begin) * A.n_samples + s0 + s] = val;
+      if (valid && (!A.debug_nostore || val == 12345.678f)) A.out[(size_t)(f - A.feat_begin) * A.out_pitch + s0 + s] = val;
       F = N;
     }
   } else {
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(BATCH_THREADS) void k_eval_batch(BatchArgs A) {
                        (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
                        (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
       const float val = (float)code;
-      if (valid && (!A.debug_nostore || val == 12345.678f)) A.out[(size_t)(f - A.feat_begin) * A.n_samples + s0 + s] = val;
+      if (valid && (!A.debug_nostore || val == 12345.678f)) A.out[(size_t)(f - A.feat_begin) * A.out_pitch + s0 + s] = val;
     }
   }
 }
@@ -302,14 +303,14 @@ __global__ __launch_bounds__(BATCH_THREADS) void k_eval_batch_wide(BatchArgs A) 
     const float y1 = refined_rcp(nf);
     auto eval = [&](const HaarFeatDev& F, int f) {
       if (A.debug_nostore == 2) {  // timing experiment: the store stream alone
-        if (valid) out[(size_t)(f - A.feat_begin) * A.n_samples] = F.w[0];
+        if (valid) out[(size_t)(f - A.feat_begin) * A.out_pitch] = F.w[0];
         return;
       }
       float ret = F.w[0] * (float)(at(F.p[0][0]) - at(F.p[0][1]) - at(F.p[0][2]) + at(F.p[0][3])) +
                   F.w[1] * (float)(at(F.p[1][0]) - at(F.p[1][1]) - at(F.p[1][2]) + at(F.p[1][3]));
       if (F.w[2] != 0.0f) ret += F.w[2] * (float)(at(F.p[2][0]) - at(F.p[2][1]) - at(F.p[2][2]) + at(F.p[2][3]));
       const float val = A.normalized ? (nf == 0.0f ? 0.0f : div_by_refined(ret, nf, y1)) : ret;
-      if (valid && (A.debug_nostore != 1 || val == 12345.678f)) out[(size_t)(f - A.feat_begin) * A.n_samples] = val;
+      if (valid && (A.debug_nostore != 1 || val == 12345.678f)) out[(size_t)(f - A.feat_begin) * A.out_pitch] = val;
     };
     // Two features per trip: their records (scalar loads, wave-uniform) are requested together. Scalar loads and LDS reads
     // share one completion counter and scalar data may return out of order, so a wavefront cannot wait for an LDS read
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(BATCH_THREADS) void k_eval_batch_wide(BatchArgs A) 
                        (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
                        (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
       const float val = (float)code;
-      if (valid && (!A.debug_nostore || val == 12345.678f)) out[(size_t)(f - A.feat_begin) * A.n_samples] = val;
+      if (valid && (!A.debug_nostore || val == 12345.678f)) out[(size_t)(f - A.feat_begin) * A.out_pitch] = val;
     };
     for (int f = f0 + wave; f < f1; f += 2 * WAVES) {
       const bool two = f + WAVES < f1;
@@ -545,7 +546,7 @@ cc_status eval_device(cc_evaluator* e) {
 }
 
 cc_status launch_batch(cc_evaluator* e, bool haar, const void* feats, int fb, int fe, const int32_t* d_idx, int ns,
-                       float* d_out_ptr, int normalized) {
+                       float* d_out_ptr, int normalized, size_t out_pitch) {
   BatchArgs A;
   A.sum = e->d_sum.p;
   A.tilted = e->use_tilted ? e->d_tilted.p : nullptr;
@@ -558,6 +559,7 @@ cc_status launch_batch(cc_evaluator* e, bool haar, const void* feats, int fb, in
   A.feat_end = fe;
   A.feats = feats;
   A.out = d_out_ptr;
+  A.out_pitch = out_pitch ? out_pitch : (size_t)ns;
   A.normalized = normalized;
   A.debug_nostore = std::getenv("CCAMD_DEBUG_EVAL_NOSTORE") ? std::max(1, std::atoi(std::getenv("CCAMD_DEBUG_EVAL_NOSTORE"))) : 0;
   A.use_tilted = e->use_tilted ? 1 : 0;
@@ -774,9 +776,33 @@ cc_status cc_eval_calc_batch(cc_evaluator* e, int fi_begin, int fi_end, const in
     CC_HIP(e->d_out.ensure(total));
     dst = e->d_out.p;
   }
-  st = launch_batch(e, haar, feats, fi_begin, fi_end, d_idx, n_samples, dst, 1);
+  st = launch_batch(e, haar, feats, fi_begin, fi_end, d_idx, n_samples, dst, 1, 0);
   if (st != CC_OK) return st;
   if (!out_on_device) CC_HIP(hipMemcpyAsync(out, dst, total * 4, hipMemcpyDeviceToHost, e->stream));
+  CC_HIP(hipStreamSynchronize(e->stream));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_ms = ms;
+  return CC_OK;
+}
+
+cc_status cc_eval_calc_batch_device(cc_evaluator* e, int fi_begin, int fi_end, const int32_t* sample_idx, int n_samples,
+                                    float* d_out, size_t pitch) {
+  if (!e || !d_out) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_batch_device: null argument");
+  if (fi_begin < 0 || fi_end > e->nfeat || fi_begin > fi_end)
+    return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc_batch_device: features [%d, %d) out of range (%d)", fi_begin, fi_end, e->nfeat);
+  if (n_samples < 0) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_batch_device: negative sample count");
+  if (pitch != 0 && pitch < (size_t)n_samples)
+    return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_batch_device: pitch %zu is smaller than the %d samples of a row", pitch, n_samples);
+  cc_status st = eval_device(e);
+  if (st != CC_OK) return st;
+  if (fi_begin == fi_end || n_samples == 0) return CC_OK;
+  std::lock_guard<std::mutex> lk(e->mu);
+  const int32_t* d_idx = nullptr;
+  st = upload_indices(e, sample_idx, n_samples, &d_idx);
+  if (st != CC_OK) return st;
+  const bool haar = e->type == CC_FEATURE_HAAR;
+  st = launch_batch(e, haar, haar ? (const void*)e->d_haar.p : (const void*)e->d_lbp.p, fi_begin, fi_end, d_idx, n_samples, d_out, 1, pitch);
+  if (st != CC_OK) return st;
   CC_HIP(hipStreamSynchronize(e->stream));
   float ms = 0;
   if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_ms = ms;
@@ -818,7 +844,7 @@ cc_status cc_eval_calc_batch_sorted(cc_evaluator* e, int fi_begin, int fi_end, i
   CC_HIP(iota.ensure(total));
   CC_HIP(sorted.ensure(total));
   CC_HIP(offsets.ensure((size_t)nf + 1));
-  st = launch_batch(e, haar, haar ? (const void*)e->d_haar.p : (const void*)e->d_lbp.p, fi_begin, fi_end, nullptr, n_samples, e->d_out.p, 1);
+  st = launch_batch(e, haar, haar ? (const void*)e->d_haar.p : (const void*)e->d_lbp.p, fi_begin, fi_end, nullptr, n_samples, e->d_out.p, 1, 0);
   if (st != CC_OK) return st;
   std::vector<int> off((size_t)nf + 1);
   for (int i = 0; i <= nf; i++) off[(size_t)i] = i * n_samples;
@@ -923,7 +949,7 @@ cc_status cc_eval_calc_custom_haar(cc_evaluator* e, const cc_haar_feature* feats
   CC_HIP(hipMemcpyAsync(e->d_custom.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice, e->stream));
   const size_t total = (size_t)n_feats * n_samples;
   CC_HIP(e->d_out.ensure(total));
-  st = launch_batch(e, true, e->d_custom.p, 0, n_feats, d_idx, n_samples, e->d_out.p, normalized ? 1 : 0);
+  st = launch_batch(e, true, e->d_custom.p, 0, n_feats, d_idx, n_samples, e->d_out.p, normalized ? 1 : 0, 0);
   if (st != CC_OK) return st;
   CC_HIP(hipMemcpyAsync(out, e->d_out.p, total * 4, hipMemcpyDeviceToHost, e->stream));
   CC_HIP(hipStreamSynchronize(e->stream));

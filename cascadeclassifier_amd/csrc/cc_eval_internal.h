@@ -66,7 +66,7 @@ struct PinnedBuf {
 cc_status eval_device(cc_evaluator* e);
 // Launches k_eval_batch over `feats` [fb, fe) for ns samples into d_out_ptr (device). Caller holds e->mu.
 cc_status launch_batch(cc_evaluator* e, bool haar, const void* feats, int fb, int fe, const int32_t* d_idx, int ns,
-                       float* d_out_ptr, int normalized);
+                       float* d_out_ptr, int normalized, size_t out_pitch /* 0 = n_samples */);
 
 }  // namespace ccamd
 

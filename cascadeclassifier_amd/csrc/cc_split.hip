@@ -310,7 +310,7 @@ cc_status cc_eval_presort_range(cc_evaluator* e, int fi_begin, int fi_end, int n
       const int f1 = std::min(F, f0 + FB);
       const size_t total = (size_t)(f1 - f0) * N;
       CC_HIP(e->d_out.ensure(total));
-      st = launch_batch(e, false, feats, fi_begin + f0, fi_begin + f1, nullptr, N, e->d_out.p, 1);
+      st = launch_batch(e, false, feats, fi_begin + f0, fi_begin + f1, nullptr, N, e->d_out.p, 1, 0);
       if (st != CC_OK) return st;
       hipLaunchKernelGGL(k_codes_u8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, e->d_out.p,
                          e->d_codes.p + (size_t)f0 * N, total);
@@ -344,7 +344,7 @@ cc_status cc_eval_presort_range(cc_evaluator* e, int fi_begin, int fi_end, int n
   for (int f0 = 0; f0 < F; f0 += FB) {
     const int f1 = std::min(F, f0 + FB), nf = f1 - f0;
     const size_t total = (size_t)nf * N;
-    st = launch_batch(e, true, feats, fi_begin + f0, fi_begin + f1, nullptr, N, e->d_out.p, 1);
+    st = launch_batch(e, true, feats, fi_begin + f0, fi_begin + f1, nullptr, N, e->d_out.p, 1, 0);
     if (st != CC_OK) return st;
     size_t temp_bytes = 0;
     CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,

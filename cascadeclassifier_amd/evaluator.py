@@ -98,10 +98,11 @@ class CvFeatureEvaluator:
         L.check(L.lib().cc_eval_calc_batch_sorted(self._e, int(fi_begin), int(fi_end), ns, _vp(vals), _vp(idx), idx_bytes))
         return vals, idx
 
-    def calc_batch_device(self, fi_begin, fi_end, out_ptr, sample_idx=None, n_samples=None):
+    def calc_batch_device(self, fi_begin, fi_end, out_ptr, sample_idx=None, n_samples=None, pitch=0):
+        """Values into device memory at out_ptr, rows `pitch` floats apart (0 = densely packed)."""
         idx = None if sample_idx is None else np.ascontiguousarray(sample_idx, np.int32)
         ns = len(idx) if idx is not None else (self.maxSampleCount if n_samples is None else n_samples)
-        L.check(L.lib().cc_eval_calc_batch(self._e, int(fi_begin), int(fi_end), _vp(idx), ns, C.c_void_p(out_ptr), 1))
+        L.check(L.lib().cc_eval_calc_batch_device(self._e, int(fi_begin), int(fi_end), _vp(idx), ns, C.c_void_p(out_ptr), int(pitch)))
 
     def calc_custom_haar(self, feats, normalized=False, sample_idx=None, n_samples=None) -> np.ndarray:
         """feats: list of (tilted, [(x, y, w, h, weight), ...]) — Feature::calc on stored samples."""

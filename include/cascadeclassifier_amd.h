@@ -282,6 +282,12 @@ CC_API cc_status cc_eval_calc_list(cc_evaluator* e, const int32_t* feature_idx, 
  * out_on_device != 0 (then it is memory of the evaluator's device). */
 CC_API cc_status cc_eval_calc_batch(cc_evaluator* e, int fi_begin, int fi_end, const int32_t* sample_idx, int n_samples,
                                     float* out, int out_on_device);
+/* The same into DEVICE memory with a row pitch: d_out[(fi - fi_begin) * pitch + s], pitch in elements (0 = n_samples).
+ * For consumers that stay on the device (presort, split search, a trainer holding valCache in HBM): the pitch lets rows
+ * start on any alignment the consumer likes; measured in round 3, the store rate of the bulk evaluator does not depend
+ * on it (profiles/r03_training_kernels.txt). */
+CC_API cc_status cc_eval_calc_batch_device(cc_evaluator* e, int fi_begin, int fi_end, const int32_t* sample_idx, int n_samples,
+                                           float* d_out, size_t pitch);
 /* cc_eval_calc_batch plus, per feature, the argsort of the samples by value: the "sorted index" half of
  * CvCascadeBoostTrainData::precalculate (FeatureValAndIdxPrecalc / FeatureIdxOnlyPrecalc,
  * o_cvcascadeboosttraindata.cpp:490-556: `buf` rows of unsigned short when sample_count < 65536, else int).

@@ -330,3 +330,23 @@ def test_feature_list_of_one_sample_matches_the_bulk_values(ftype, mode):
         e.calc_list([F], 0)
     with pytest.raises(cc.CascadeError):
         e.calc_list([0], 6)
+
+
+def test_bulk_values_into_pitched_device_memory():
+    """cc_eval_calc_batch_device: rows `pitch` floats apart in device memory; the padding is left untouched."""
+    import torch
+    rng = np.random.default_rng(5)
+    imgs = rng.integers(0, 256, (100, 24, 24), dtype=np.uint8)
+    e = cc.CvFeatureEvaluator.create(0)
+    e.init(cc.CvFeatureParams(0, 0), 100, (24, 24))
+    e.setImages(imgs)
+    want = e.calc_batch(1000, 1300)
+    for pitch in (0, 100, 128, 133):
+        p = pitch or 100
+        out = torch.full((300, p), -7.0, dtype=torch.float32, device="cuda")
+        e.calc_batch_device(1000, 1300, out.data_ptr(), n_samples=100, pitch=pitch)
+        got = out.cpu().numpy()
+        assert (got[:, :100].view(np.uint32) == want.view(np.uint32)).all()
+        assert (got[:, 100:] == -7.0).all()
+    with pytest.raises(cc.CascadeError):
+        e.calc_batch_device(0, 10, torch.empty(10, 100, device="cuda").data_ptr(), n_samples=100, pitch=64)

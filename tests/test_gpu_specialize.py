@@ -132,6 +132,36 @@ def test_noinline_generated_stages_match(lbp_xml, haar_xml, monkeypatch):
         assert _same_as_oracle(p, orc.load_cascade_xml(xml), img, 1.1) > 0
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("wave_below,split", [(24, 1), (8, 1), (64, 1), (0, 1), (24, 0)])
+def test_every_late_stage_shape_in_one_launch(haar_xml, wave_below, split, monkeypatch):
+    """Regression shape for the round-2 stall record ("incident records"): ONE launch in which some tiles
+    carry long queues through the late stages (pasted face templates: whole rounds of row groups plus leftover groups
+    that are split by stumps, ns > 1, with the extra block barrier of that path), others drop below `wave_below` at
+    different stages (wave phase) and others empty out early -- under every setting of the switches that choose
+    between those paths. Every barrier of the kernel sits on a block-uniform condition; if one did not, this launch
+    would hang (the timeout fails the test) or diverge from the oracle."""
+    monkeypatch.setenv("CCAMD_WAVE_BELOW", str(wave_below))
+    monkeypatch.setenv("CCAMD_SPLIT_STUMPS", str(split))
+    import os
+    from tests.util import upscale
+    tm = np.load(os.path.join(os.path.dirname(haar_xml), "face_template_24x24.npy"))
+    img = frame_natural(704, 396, 5)
+    img[200:, :352] = frame_uniform(352, 196, 6)           # tiles that empty out in stage 0-1
+    img[:60, 400:] = 128                                    # flat: every window fails the variance test
+    rng = np.random.default_rng(3)
+    for k in (1.0, 1.0, 1.1, 1.21, 1.6, 2.0, 2.7, 4.0):     # faces: queues that stay long into the late stages
+        s_ = int(24 * k)
+        y, x = int(rng.integers(0, 396 - s_)), int(rng.integers(0, 704 - s_))
+        img[y:y + s_, x:x + s_] = upscale(tm, s_)
+    o = orc.load_cascade_xml(haar_xml)
+    p = cc.CascadeClassifier(haar_xml)
+    n = _same_as_oracle(p, o, img, 1.1)                     # table-driven kernel
+    assert p.specialize(7) == 7
+    n += _same_as_oracle(p, o, img, 1.1)
+    assert n > 8
+
+
 def test_tile16_kernels_match(lbp_xml, haar_xml, tmp_path, monkeypatch):
     """CCAMD_SPEC_TILE16=1: STEP-2 tiles hold the low 16 bits of the integral (half the LDS bytes, 7-8 resident blocks
     per CU). Rectangle sums are exact modulo 2^16 while 255 * area < 2^16; larger rectangles are generated as strips that

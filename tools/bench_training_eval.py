@@ -42,6 +42,22 @@ def main():
     t_set = time.perf_counter() - t0
 
     block = 32768
+    # does the rate of the bulk evaluator depend on the pitch of the output rows? The trainer's layout
+    # is out[feature][sample] (one row per feature, o_cvcascadeboosttraindata.cpp:582-596): every wavefront stores a 256-byte
+    # piece `pitch` floats away from the previous feature's. 20 000 floats = 80 000 B = 2^7 x 625; padded pitches move the
+    # rows onto other channel / bank phases.
+    pitches = [int(v) for v in os.environ.get("CCAMD_BENCH_PITCHES", "20000,20032,20096,20480").split(",")]
+    sweep = {}
+    out = torch.empty((block, max(pitches + [N])), dtype=torch.float32, device="cuda")
+    for pitch in pitches:
+        e.calc_batch_device(0, block, out.data_ptr(), n_samples=N, pitch=pitch)  # warm-up
+        torch.cuda.synchronize()
+        ms = 0.0
+        for f0 in range(0, nfeat, block):
+            f1 = min(f0 + block, nfeat)
+            e.calc_batch_device(f0, f1, out.data_ptr(), n_samples=N, pitch=pitch)
+            ms += e.last_kernel_ms()
+        sweep[str(pitch)] = {"kernel_ms": round(ms, 3), "write_TBps": round(nfeat * N * 4 / (ms * 1e-3) / 1e12, 3)}
     out = torch.empty((block, N), dtype=torch.float32, device="cuda")
     e.calc_batch_device(0, block, out.data_ptr(), n_samples=N)  # warm-up
     torch.cuda.synchronize()
@@ -75,6 +91,7 @@ def main():
         "hbm_write_GBps_kernel": round(evals * 4 / (kernel_ms * 1e-3) / 1e9, 1),
         "frac_of_8TBps": round(evals * 4 / (kernel_ms * 1e-3) / 8e12, 4),
         "slice_bit_identical_to_oracle": same,
+        "row_pitch_sweep": sweep,
         "cpu_oracle_mevals_per_s_1thread": round((f1 - f0) * N / t_cpu / 1e6, 1),
     }))
 

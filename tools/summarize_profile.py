@@ -44,6 +44,6 @@ for k, v in summary["kernels"].items():
                    "kernel": k, "kernel_src_sha16": summary["kernel_src_sha16"], "frames_per_launch": fpl, "fetch_correction": 2.0,
                    "fetch_size_kb_raw_per_launch": v["FETCH_SIZE_KB_per_launch_raw"], "write_size_kb_raw_per_launch": v["WRITE_SIZE_KB_per_launch_raw"],
                    "hbm_bytes_per_frame": (2.0 * v["FETCH_SIZE_KB_per_launch_raw"] + v["WRITE_SIZE_KB_per_launch_raw"]) * 1024 / fpl},
-                  open("profiles/r02_traffic_k_eval.json", "w"), indent=1)
+                  open(f"profiles/{dst_prefix.split('_')[0]}_traffic_k_eval.json", "w"), indent=1)
 json.dump(summary, open(f"profiles/{dst_prefix}_summary.json", "w"), indent=1)
 print(json.dumps(summary["kernels"], indent=1))
