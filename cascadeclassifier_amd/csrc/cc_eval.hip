@@ -316,6 +316,9 @@ __global__ __launch_bounds__(BATCH_THREADS) void k_eval_batch_wide(BatchArgs A) 
     // share one completion counter and scalar data may return out of order, so a wavefront cannot wait for an LDS read
     // while a scalar load is in flight without waiting for that load too: a record fetch cannot be overlapped with the
     // evaluation of the previous feature, only amortised over more features.
+    // (Round 3 tried requesting the NEXT trip's records before this trip's LDS reads, so that their latency runs under the
+    // LDS round trip: the arithmetic alone got 10 % faster (5.9 -> 5.3 ms without the stores), the kernel did not
+    // (6.57 vs 6.43 ms): the store stream alone takes 5.8 ms and is what bounds it. Not kept.)
     for (int f = f0 + wave; f < f1; f += 2 * WAVES) {
       const bool two = f + WAVES < f1;
       const HaarFeatDev Fa = load_feat(feats + f), Fb = load_feat(feats + (two ? f + WAVES : f));
