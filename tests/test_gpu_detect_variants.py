@@ -87,6 +87,29 @@ def test_windows_other_than_24x24(tmp_path, W, H):
     assert n > 0
 
 
+@pytest.mark.parametrize("W,H", [(20, 20), (31, 57), (75, 32), (96, 96), (25, 24)])
+def test_specialised_windows_other_than_24x24(tmp_path, W, H):
+    """The same cascades with EVERY stage compiled (cc_detector_specialize): an LBP cascade compiled whole takes the 16-bit
+    STEP-2 tile (TileGeom16) when all its cells sum below 2^16 -- 20x20, 31x57, 25x24 and 75x32 do, 96x96 has cells of up
+    to 32x32 pixels and keeps the 32-bit tile -- so tile geometry, row pitch and bank skew of both layouts are exercised for
+    even and odd window sizes."""
+    xml = cf.lbp_stump_cascade(W, H)
+    path = os.path.join(str(tmp_path), "cascade.xml")
+    open(path, "w").write(xml)
+    o = orc.load_cascade_xml(path)
+    p = cc.CascadeClassifier(path)
+    assert p.specialize(3) == 3
+    n = 0
+    for img, sf in ((frame_natural(400, 300, 51), 1.1), (frame_natural(W + 3, H + 40, 52), 1.5), (frame_uniform(333, 127, 53), 1.25)):
+        ref = orc.detect_raw(o, img, sf, nthreads=8, full=True)
+        codes, sums, vis = p.debug_windows(img, sf)
+        assert (codes == ref.codes).all() and (sums == ref.sums).all() and (vis == ref.visited).all()
+        raw = p.detect_raw(img, sf)
+        assert raw.shape == ref.candidates.shape and (raw == ref.candidates).all()
+        n += len(raw)
+    assert n > 0
+
+
 @pytest.mark.parametrize("which", ["haar", "lbp", "haar_specialised"])
 def test_output_reject_levels_overload(which, haar_xml, lbp_xml):
     """detectMultiScale(objects, rejectLevels, levelWeights, ..., outputRejectLevels=true): rectangles, levels (= number of
