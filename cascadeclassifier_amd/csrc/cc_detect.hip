@@ -851,7 +851,8 @@ struct cc_detector {
   DevBuf<HaarStumpDev> d_haar1, d_haar2;
   DevBuf<HaarStumpDev> d_haar1w, d_haar2w;  // the same stumps dealt to lanes for the wave phase (bank-aware order)
   DevBuf<HaarStumpDev> d_haar_g;            // corners as window coordinates (GlobalReader; kernels with 16-bit tiles)
-  DevBuf<LbpStumpDev> d_lbp_g;
+  DevBuf<LbpStumpDev> d_lbp_g, d_lbp16;      // LBP: window coordinates (GlobalReader) / 16-bit STEP-2 tile offsets (LBP wave phase)
+  int lbp16_all = 0;                        // every LBP cell of the cascade sums below 2^16
   DevBuf<LbpStumpDev> d_lbp1, d_lbp2;
   DevBuf<HaarNodeDev> d_hnode1, d_hnode2;  // cascades with trees deeper than stumps
   DevBuf<LbpNodeDev> d_lnode1, d_lnode2;
@@ -1975,6 +1976,8 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.wstumps1 = d->d_haar1w.p ? (const void*)d->d_haar1w.p : A.stumps1;
     A.wstumps2 = d->d_haar2w.p ? (const void*)d->d_haar2w.p : A.stumps2;
     A.gstumps = haar ? (const void*)d->d_haar_g.p : (const void*)d->d_lbp_g.p;
+    A.lbp16_all = d->lbp16_all;
+    if (!haar && d->d_lbp16.p) A.wstumps2 = d->d_lbp16.p;  // LBP wave phase of kernels with 16-bit tiles
     A.trees = d->m.max_nodes_per_tree > 1 ? 1 : 0;
     A.nodes1 = haar ? (const void*)d->d_hnode1.p : (const void*)d->d_lnode1.p;
     A.nodes2 = haar ? (const void*)d->d_hnode2.p : (const void*)d->d_lnode2.p;
@@ -2628,6 +2631,13 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   const bool trees = d->m.max_nodes_per_tree > 1;  // general trees: thread-per-window phases only, sequential sums
   const bool exact = !trees && stage_sums_order_independent(d->m);
   d->wave_below = (haar && exact) ? 24 : 0;
+  if (!haar && !trees) {
+    // LBP wave phase (lanes = the stumps of several whole stages; sums in stump order, so no exactness condition): needs
+    // every stage to fit a wavefront. Threshold measured on the stock cascade (tools/sweeps/r3_l.txt).
+    bool fits = true;
+    for (int v : d->m.stage_ntrees) fits = fits && v <= 64;
+    d->wave_below = fits ? 24 : 0;  // 8 ... 32 within 3 % of each other, 48 +5 %, 64 +11 %, off +23 %
+  }
   d->split_stumps = exact ? 1 : 0;
   if (const char* e = std::getenv("CCAMD_SPLIT_STUMPS")) d->split_stumps = d->split_stumps && std::atoi(e) != 0;
   if (const char* e = std::getenv("CCAMD_DEBUG_STOP_AFTER_STAGE")) d->stop_after = std::atoi(e);  // timing experiments
@@ -2642,7 +2652,7 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
     if (d->lds > 64 * 1024)
       CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(haar ? &k_eval_haar : &k_eval_lbp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds));
   }
-  if (const char* e = std::getenv("CCAMD_WAVE_BELOW"))  // tuning knob; only honoured when the reduction is exact
+  if (const char* e = std::getenv("CCAMD_WAVE_BELOW"))  // tuning knob; only honoured where the wave phase is valid at all
     if (d->wave_below) d->wave_below = std::max(0, std::min(64, std::atoi(e)));  // the wave phase holds one window per lane
   CC_HIP(d->d_stage_thr.upload(d->m.stage_threshold, d->stream));
   {
@@ -2658,7 +2668,9 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
     // group keep executing; the gain is in the LATE stages, where a handful of windows per tile pay a barrier round per
     // stage. Hence two knobs: groups start at stage `from`, and hold up to `budget` stumps.
     const bool lbp = !haar && !trees;
-    int budget = lbp ? 30 : 0, from = lbp ? 4 : 1;  // LBP: 7.63 -> 7.51 (32-bit tile), 6.72 -> 6.67 (16-bit tile)
+    // LBP with its wave phase (which takes over below 24 windows): groups of <= 20 stumps from stage 2 on 4.91-5.06,
+    // 12 from stage 1: 5.04-5.25, one stage per group 5.29, 30 from stage 2: 5.36
+    int budget = lbp ? 20 : 0, from = lbp ? 2 : 1;
     if (const char* e = std::getenv("CCAMD_GROUP_STUMPS")) budget = trees ? 0 : std::max(0, std::atoi(e));  // tuning
     if (const char* e = std::getenv("CCAMD_GROUP_FROM")) from = std::max(1, std::atoi(e));
     std::vector<int> gf;
@@ -2719,9 +2731,18 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
     build_lbp_stumps<2>(d->m, s2);
     CC_HIP(d->d_lbp1.upload(s1, d->stream));
     CC_HIP(d->d_lbp2.upload(s2, d->stream));
-    std::vector<LbpStumpDev> sg;
+    std::vector<LbpStumpDev> sg, s16;
     build_lbp_gstumps(d->m, sg);
     CC_HIP(d->d_lbp_g.upload(sg, d->stream));
+    d->lbp16_all = 1;
+    for (size_t i = 0; i < d->m.stump_feature.size(); i++) {
+      const int32_t* r = &d->m.lbp_rects[(size_t)d->m.stump_feature[i] * 4];
+      if (!fits16((long long)r[2] * r[3])) d->lbp16_all = 0;
+    }
+    if (d->lbp16_all) {
+      build_lbp_stumps16(d->m, s16);
+      CC_HIP(d->d_lbp16.upload(s16, d->stream));
+    }
     CC_HIP(hipStreamSynchronize(d->stream));
   }
   // CCAMD_AUTO_SPECIALIZE=<stages>: build the specialised kernel in the background; detection starts on the table-driven

@@ -162,6 +162,29 @@ def test_every_late_stage_shape_in_one_launch(haar_xml, wave_below, split, monke
     assert n > 8
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("wave_below", [0, 8, 24, 64])
+def test_lbp_wave_phase_thresholds(lbp_xml, tmp_path, wave_below, monkeypatch):
+    """LBP wave phase (below `wave_below` windows a wavefront takes a window and its lanes the stumps of several whole
+    stages; per-stage sums in stump order): every threshold, specialised (16-bit tile) and table-driven kernel, must give
+    the oracle's codes, exit stages and stage sums. A cascade with a stage of more than 64 stumps cannot use it (a stage
+    must fit a wavefront) and must still be right."""
+    monkeypatch.setenv("CCAMD_WAVE_BELOW", str(wave_below))
+    img, img2 = frame_natural(640, 360, 11), frame_uniform(300, 200, 12)
+    o = orc.load_cascade_xml(lbp_xml)
+    p = cc.CascadeClassifier(lbp_xml)
+    n = _same_as_oracle(p, o, img, 1.1)
+    assert p.specialize(20) == 20
+    n += _same_as_oracle(p, o, img, 1.1) + _same_as_oracle(p, o, img2, 1.25)
+    assert n > 0
+    long_stage = cf.lbp_stump_cascade(24, 24, seed=9, stage_sizes=(3, 70, 5, 4))
+    path = str(tmp_path / "long.xml")
+    open(path, "w").write(long_stage)
+    q = cc.CascadeClassifier(path)
+    assert q.specialize(4) == 4
+    assert _same_as_oracle(q, orc.load_cascade_xml(path), img2, 1.2) >= 0
+
+
 def test_tile16_kernels_match(lbp_xml, haar_xml, tmp_path, monkeypatch):
     """CCAMD_SPEC_TILE16=1: STEP-2 tiles hold the low 16 bits of the integral (half the LDS bytes, 7-8 resident blocks
     per CU). Rectangle sums are exact modulo 2^16 while 255 * area < 2^16; larger rectangles are generated as strips that

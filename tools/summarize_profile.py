@@ -11,14 +11,15 @@ import sys
 tag, dst_prefix = sys.argv[1], sys.argv[2]
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0]
+newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]  # a tag may have been profiled more than once
+stats = newest(f"{src}/stats/*/*kernel_stats.csv")[0]
 shutil.copy(stats, f"profiles/{dst_prefix}_kernel_stats.csv")
 summary = {"kernels": {}}
 for r in csv.DictReader(open(stats)):
     summary["kernels"][r["Name"].split("(")[0]] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                                                     "pct": float(r["Percentage"])}
 for name, counter in (("pmc_rd", "FETCH_SIZE"), ("pmc_wr", "WRITE_SIZE")):
-    f = glob.glob(f"{src}/{name}/*/*counter_collection.csv")
+    f = newest(f"{src}/{name}/*/*counter_collection.csv")
     if not f:
         continue
     agg = collections.defaultdict(list)
