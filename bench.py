@@ -105,16 +105,24 @@ def measure_extra_workload(cc, torch, dev, dev_index, cascade, specialize, frame
     ipx = int(((plan["w"] + 1).astype(np.int64) * (plan["h"] + 1)).sum())
     bytes_frame = (8 if inf["feature_type"] == 0 else 4) * ipx
 
-    def step():
-        return clf.detect_batch(None, args.scale_factor, args.min_neighbors, device_ptr=frames.data_ptr(), shape=(B, H, W))
-    step()
+    def run(k):  # the headline's step form: pipelined submit / collect unless --sync-steps
+        out, prev = None, None
+        for _ in range(k):
+            if args.sync_steps:
+                out = clf.detect_batch(None, args.scale_factor, args.min_neighbors, device_ptr=frames.data_ptr(), shape=(B, H, W))
+                continue
+            t = clf.detect_batch_submit(None, args.scale_factor, args.min_neighbors, device_ptr=frames.data_ptr(), shape=(B, H, W))
+            if prev is not None:
+                out = clf.detect_batch_collect(prev)
+            prev = t
+        return clf.detect_batch_collect(prev) if prev is not None else out
+    run(1)
     clf.set_profiling(True)
     clf.timings(reset=True)
     torch.cuda.synchronize()
-    steps = max(2, min(args.steps, 4))
+    steps = max(2, min(args.steps, 6))
     t0 = time.perf_counter()
-    for _ in range(steps):
-        last = step()
+    last = run(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tm = clf.timings(reset=True)
@@ -182,6 +190,8 @@ def main():
     ap.add_argument("--specialize", type=int, default=7, help="stages compiled into the cascade kernel at load time (hiprtc; 0 = "
                                                               "table-driven kernel only)")
     ap.add_argument("--device-only", action="store_true", help="time the device pipeline only (no copy-back/grouping)")
+    ap.add_argument("--sync-steps", action="store_true", help="one synchronous cc_detect_batch call per step instead of pipelined "
+                                                            "submit / collect (the headline of rounds 1-2)")
     ap.add_argument("--no-extra", action="store_true", help="skip the legs reported beside the headline (host split, host-frame "
                                                           "call shape, LBP cascade, uniform-noise frames); rank 0 at N = 1 only")
     ap.add_argument("--cpu-reps", type=int, default=5, help="repetitions of the CPU-baseline sample (median is reported)")
@@ -263,20 +273,42 @@ def main():
             rects = gather_detections(rects, device=comm_dev, comm=comm)
         return rects
 
+    def run_steps(k):
+        """k steps. Default: the steps are PIPELINED through cc_detect_batch_submit / _collect -- step i + 1 is submitted
+        before step i is collected, so its pyramid / integral work runs under the cascade kernel of step i and step i's
+        copy-back and grouping under the device side of step i + 1 (the C ABI's form for streams of batches). Every step is
+        submitted, collected and (N > 1) gathered inside the call: nothing is left in flight when it returns.
+        --sync-steps: one synchronous cc_detect_batch per step."""
+        if args.device_only or args.sync_steps:
+            out = None
+            for _ in range(k):
+                out = step()
+            return out
+        out, prev = None, None
+        for _ in range(k):
+            t = clf.detect_batch_submit(None, args.scale_factor, args.min_neighbors, device_ptr=frames.data_ptr(), shape=(B, H, W))
+            if prev is not None:
+                out = clf.detect_batch_collect(prev)
+                if world > 1:
+                    out = gather_detections(out, device=comm_dev, comm=comm)
+            prev = t
+        if prev is not None:
+            out = clf.detect_batch_collect(prev)
+            if world > 1:
+                out = gather_detections(out, device=comm_dev, comm=comm)
+        return out
+
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     clf.set_profiling(True)
     clf.timings(reset=True)
     sync()
     t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()
+    last = run_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
     tm = clf.timings(reset=True)
@@ -301,7 +333,15 @@ def main():
             clf.run_device_only(frames.data_ptr(), (B, H, W), args.scale_factor)
         torch.cuda.synchronize()
         dev_ms = (time.perf_counter() - t1) / k * 1e3
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        sync_ms = (time.perf_counter() - t1) / k * 1e3
         host_split = {"device_pipeline_only_ms_per_step": round(dev_ms, 4),
+                      "synchronous_call_ms_per_step": round(sync_ms, 4),
+                      "synchronous_call_value": round(windows_per_frame * B / (sync_ms * 1e-3) / 1e6, 3),
                       "host_ms_per_step": round(dt / args.steps * 1e3 - dev_ms, 4),
                       "what": "ms_per_step minus the same step without candidate copy-back, host grouping and Python list building (device "
                               f"pipeline only, {k} steps after the timed region); the device legs of the passes overlap, so kernel_ms_per_step does not add up to either"}
@@ -385,6 +425,9 @@ def main():
             "frame_content": ("1/f noise (sigma 40)" if args.content == "natural" else "i.i.d. uniform noise") + " + 5 pasted face templates",
             "parallelism": f"frames sharded over {world} GPU(s); RCCL gather of detections only",
             "gather": gather_kind,
+            "steps_are": "device pipeline only" if args.device_only else ("synchronous cc_detect_batch calls" if args.sync_steps else
+                         "pipelined: cc_detect_batch_submit(step i + 1) before cc_detect_batch_collect(step i); every step submitted, "
+                         "collected and gathered inside the timed region"),
             "timed_region": "device pipeline only" if args.device_only else
                             "pyramid+integral+cascade eval+skip filter+candidate copy-back+host grouping" + ("+RCCL gather" if world > 1 else ""),
         },

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <thread>
 
@@ -829,6 +830,14 @@ struct TimingEvent {
   int kind;
 };
 
+// Where the filtered candidates of a batch's passes go (called on the host thread that retires the pass), and the first
+// error met while retiring one of its passes from another call (cc_detect_batch_submit of the NEXT batch).
+struct BatchSink {
+  std::function<void(int f0, int nf, std::vector<CandOut>& cands)> consume;
+  cc_status status = CC_OK;
+  std::string error;
+};
+
 }  // namespace ccamd
 
 using namespace ccamd;
@@ -884,8 +893,11 @@ struct cc_detector {
   int spec_bg_stages = 0;
   bool spec_bg_tile16 = false;
   std::string spec_bg_error;
-  DevBuf<unsigned long long> d_masks;
-  DevBuf<CandRaw> d_cands;
+  // Per slot, like the results. (Round 3 also ran the cascade kernels of consecutive passes on two streams, so that the next
+  // one starts on the CUs the previous one's last blocks leave free: 18.50 -> 19.24 ms per step, two kernels of this size
+  // only get in each other's way. Not kept.)
+  DevBuf<unsigned long long> d_masks[2];
+  DevBuf<CandRaw> d_cands[2];
   // Results of a pass are double-buffered so that the host can fetch and group pass i while the device runs pass i+1.
   DevBuf<CandOut> d_out[2];
   DevBuf<int> d_counts[2];  // [0] raw count, [1] filtered count
@@ -897,6 +909,22 @@ struct cc_detector {
   hipStream_t copy_stream = nullptr;
   hipEvent_t pass_done[2] = {nullptr, nullptr};
   int cand_cap = 0;
+  // The pass launched last, not yet fetched (run_batch): inside a batch that is what lets the host side of pass i overlap
+  // the device side of pass i + 1; across calls (cc_detect_batch_submit) it lets the first pass of the next batch overlap
+  // the last pass of this one. `sink` receives the pass's candidates when it is retired.
+  struct PendingPass {
+    bool active = false;
+    Plan* plan = nullptr;
+    int f0 = 0, nf = 0, slot = 0;
+    const uint8_t* dptr = nullptr;
+    size_t rs = 0, fs = 0;
+    int cap = 0;       // capacity of the candidate lists the pass was launched with
+    unsigned gen = 0;  // generation of the candidate lists it wrote into
+    bool debug = false;
+    std::shared_ptr<ccamd::BatchSink> sink;
+  } pending;
+  unsigned list_gen = 0;  // bumped whenever the candidate lists are released and regrown
+  int next_slot = 0;      // result / integral slot the next pass uses (alternates, also across calls)
   DevBuf<unsigned long long> d_stamps;  // CCAMD_DEBUG_STAMPS experiments
   DevBuf<int32_t> d_dbg_codes;
   DevBuf<double> d_dbg_sums;
@@ -913,6 +941,7 @@ struct cc_detector {
     }
     if (own_stream) (void)hipStreamDestroy(own_stream);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+
     if (front_stream) (void)hipStreamDestroy(front_stream);
     if (spec_thread.joinable()) spec_thread.join();
     if (spec_mod) (void)hipModuleUnload(spec_mod);
@@ -1905,9 +1934,9 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     CC_HIP(d->d_diag.ensure(P->int_frame_elems * 2 * (size_t)d->pass_capacity));
     CC_HIP(d->d_tseg.ensure(std::max<size_t>(P->tilt.frame_elems * (size_t)d->pass_capacity, 1)));
   }
-  CC_HIP(d->d_masks.ensure(std::max<size_t>(P->mask_frame_words * (size_t)d->pass_capacity, 1)));
+  CC_HIP(d->d_masks[slot].ensure(std::max<size_t>(P->mask_frame_words * (size_t)d->pass_capacity, 1)));
   if (d->cand_cap == 0) d->cand_cap = 1 << 18;
-  CC_HIP(d->d_cands.ensure((size_t)d->cand_cap));
+  CC_HIP(d->d_cands[slot].ensure((size_t)d->cand_cap));
   CC_HIP(d->d_out[slot].ensure((size_t)d->cand_cap));
   if (debug) {
     CC_HIP(d->d_dbg_codes.ensure((size_t)std::max<long long>(P->windows, 1)));
@@ -1957,9 +1986,9 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.early_skip = d->early_skip;
     A.sq_compact = sq_compact;
     A.stage_thr = d->d_stage_thr.p;
-    A.masks = d->d_masks.p;
+    A.masks = d->d_masks[slot].p;
     A.mask_frame_words = P->mask_frame_words;
-    A.cands = d->d_cands.p;
+    A.cands = d->d_cands[slot].p;
     A.cand_count = d->d_counts[slot].p;
     A.cand_cap = d->cand_cap;
     A.stamps = nullptr;
@@ -2000,11 +2029,11 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   }
   {
     EvScope ev(d, EV_FILTER, st);
-    hipLaunchKernelGGL(k_filter_candidates, dim3(64), dim3(256), 0, st, d->d_cands.p, d->d_counts[slot].p, d->cand_cap, P->d_sd.p,
-                       d->d_masks.p, P->mask_frame_words, d->d_out[slot].p, d->d_counts[slot].p + 1);
+    hipLaunchKernelGGL(k_filter_candidates, dim3(64), dim3(256), 0, st, d->d_cands[slot].p, d->d_counts[slot].p, d->cand_cap, P->d_sd.p,
+                       d->d_masks[slot].p, P->mask_frame_words, d->d_out[slot].p, d->d_counts[slot].p + 1);
     if (debug && P->n_grid_rows)
       hipLaunchKernelGGL(k_debug_visited, dim3(P->n_grid_rows), dim3(256), 0, st, P->d_sd.p, ns, P->d_gridrow_first.p,
-                         d->d_masks.p, d->d_dbg_visited.p);
+                         d->d_masks[slot].p, d->d_dbg_visited.p);
   }
   CC_HIP(hipGetLastError());
   if (const char* path = std::getenv("CCAMD_DEBUG_STAMPS")) {  // dump [n_tiles * nf][STAMP_SLOTS] u64 (overwritten per pass)
@@ -2034,17 +2063,88 @@ static cc_status check_frame_args(const cc_detector* d, const uint8_t* frames, i
   return CC_OK;
 }
 
+static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes, int nf, size_t row_stride,
+                                 size_t frame_stride, bool debug, int slot, bool single_stream);
+
+// Fetches the results of the pending pass and hands them to its sink. On candidate-list overflow the lists grow and the
+// pass is redone synchronously. Growing frees the lists of BOTH slots; a pass is judged against the capacity it was
+// launched with and against the generation of the lists it wrote into (stale generation => redone as well).
+static cc_status retire_pending(cc_detector* d) {
+  if (!d->pending.active) return CC_OK;
+  cc_detector::PendingPass ps = d->pending;
+  d->pending.active = false;
+  d->pending.sink.reset();
+  std::vector<CandOut> got;
+  for (;;) {
+    CC_HIP(hipEventSynchronize(d->pass_done[ps.slot]));
+    const int raw = d->h_counts[2 * ps.slot], kept = d->h_counts[2 * ps.slot + 1];
+    if (raw > ps.cap || ps.gen != d->list_gen) {
+      CC_HIP(hipStreamSynchronize(d->stream));
+      if (raw > d->cand_cap) {
+        d->cand_cap = raw + raw / 2;
+        d->d_cands[0].release();
+        d->d_cands[1].release();
+        d->d_out[0].release();
+        d->d_out[1].release();
+        d->list_gen++;
+      }
+      cc_status st2 = run_device_pass(d, ps.plan, ps.dptr, ps.nf, ps.rs, ps.fs, ps.debug, ps.slot, false);
+      if (st2 != CC_OK) return st2;
+      ps.cap = d->cand_cap;
+      ps.gen = d->list_gen;
+      CC_HIP(hipMemcpyAsync(d->h_counts + 2 * ps.slot, d->d_counts[ps.slot].p, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+      CC_HIP(hipEventRecord(d->pass_done[ps.slot], d->stream));
+      continue;
+    }
+    got.resize((size_t)kept);
+    if (kept > 0) {  // the copy stream is free to run while the main stream executes the next pass
+      CC_HIP(hipMemcpyAsync(got.data(), d->d_out[ps.slot].p, (size_t)kept * sizeof(CandOut), hipMemcpyDeviceToHost, d->copy_stream));
+      CC_HIP(hipStreamSynchronize(d->copy_stream));
+      for (CandOut& c : got) c.frame += ps.f0;
+    }
+    if (ps.sink && ps.sink->consume) ps.sink->consume(ps.f0, ps.nf, got);
+    return CC_OK;
+  }
+}
+// Retires a pass that belongs to another batch than the caller's: its failure is that batch's, reported when it is collected.
+static void retire_foreign(cc_detector* d) {
+  if (!d->pending.active) return;
+  std::shared_ptr<BatchSink> sink = d->pending.sink;
+  const cc_status st = retire_pending(d);
+  if (st != CC_OK && sink && sink->status == CC_OK) {
+    sink->status = st;
+    sink->error = cc_last_error();
+  }
+}
+
 static void spec_poll(cc_detector* d);  // installs a finished background specialisation
 
 // Runs the batch in passes. `consume` (optional) receives the filtered candidates of each pass (frame indices made
 // global) on the calling thread. With two or more frames the batch is cut into at least two passes and the host side
 // of pass i (copy-back + consume) overlaps the device side of pass i+1.
+// `defer_last`: the batch's last pass stays pending when the call returns (cc_detect_batch_submit); its candidates reach
+// `consume` when the next call -- or cc_detect_batch_collect -- retires it.
 template <class Consume>
 static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device, int n_frames, int width, int height,
                            size_t row_stride, size_t frame_stride, const cc_detect_params* p, bool want_results, bool debug,
-                           Consume consume) {
+                           Consume consume_fn, bool defer_last = false, std::shared_ptr<BatchSink> shared_sink = nullptr) {
   cc_status stt = ensure_device(d->device);
   if (stt != CC_OK) return stt;
+  std::shared_ptr<BatchSink> sink = shared_sink;
+  if (!sink) {
+    sink = std::make_shared<BatchSink>();
+    sink->consume = consume_fn;
+  }
+  auto consume = [&](int f0_, int nf_, std::vector<CandOut>& c) { sink->consume(f0_, nf_, c); };
+  // A pass of an earlier (submitted) batch may still be pending. It can stay so -- and overlap this call's first pass --
+  // only if this call runs ordinary passes on the same plan; everything else fetches it first.
+  if (d->pending.active) {
+    bool same_plan = false;
+    for (auto& pl : d->plans)
+      if (pl.get() == d->pending.plan && pl->w == width && pl->h == height && same_params(pl->p, *p)) same_plan = true;
+    const bool single_image_graph = n_frames == 1 && !on_device && want_results && !debug && !d->profiling && d->use_graph;
+    if (!same_plan || debug || !want_results || single_image_graph || n_frames < 1) retire_foreign(d);  // (a new plan may evict the pending pass's)
+  }
   spec_poll(d);
   Plan* P = nullptr;
   stt = build_plan(d, width, height, *p, &P);
@@ -2064,9 +2164,13 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       CC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     d->overlap_front = std::getenv("CCAMD_NO_FRONT_OVERLAP") ? 0 : 1;
     d->use_graph = std::getenv("CCAMD_NO_GRAPH") ? 0 : 1;
+
   }
   hipStream_t front = d->overlap_front ? d->front_stream : d->stream;
-  if (front != d->stream) {  // frames produced by earlier work on the caller's stream must be complete before the pyramid reads them
+  // Frames produced by earlier work on a stream the CALLER gave us (cc_detector_set_stream) must be complete before the
+  // pyramid reads them. On the detector's own stream there is only our own earlier work -- a pending pass of the batch
+  // submitted before -- and waiting for that would serialise exactly what cc_detect_batch_submit exists to overlap.
+  if (front != d->stream && d->stream != d->own_stream) {
     CC_HIP(hipEventRecord(d->batch_begin, d->stream));
     CC_HIP(hipStreamWaitEvent(front, d->batch_begin, 0));
   }
@@ -2090,7 +2194,7 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       return CC_OK;
     };
     auto key_now = [&]() {
-      return std::vector<const void*>{d->d_frames.p, d->h_frame, d->d_pyr.p, d->d_integ[0].p, d->d_hbuf.p, d->d_diag.p, d->d_tseg.p, d->d_masks.p, d->d_cands.p,
+      return std::vector<const void*>{d->d_frames.p, d->h_frame, d->d_pyr.p, d->d_integ[0].p, d->d_hbuf.p, d->d_diag.p, d->d_tseg.p, d->d_masks[0].p, d->d_cands[0].p,
                                       d->d_out[0].p, d->d_counts[0].p, d->h_counts, (const void*)d->spec_fn, (const void*)d->stream,
                                       (const void*)(size_t)d->cand_cap, (const void*)(size_t)d->wave_below, (const void*)(size_t)(d->stop_after + 16)};
     };
@@ -2197,61 +2301,19 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     sizes.swap(fixed);
   }
   for (int v : sizes) d->pass_capacity = std::max(d->pass_capacity, v);  // the workspace only ever grows
-  struct Pass {
-    int f0, nf, slot;
-    const uint8_t* dptr;
-    size_t rs, fs;
-    int cap;       // capacity of the candidate lists this pass was launched with
-    unsigned gen;  // generation of the candidate lists it wrote into
-  };
-  std::vector<CandOut> got;
-  unsigned list_gen = 0;  // bumped whenever the candidate lists are released and regrown
-  // Fetches the results of a launched pass. On candidate-list overflow the lists grow and the pass is redone
-  // synchronously. Growing frees the lists of BOTH slots, so the pass already in flight in the other slot loses its
-  // results: it notices (its generation is stale) when its own turn comes and is redone as well. A pass is judged
-  // against the capacity it was launched with, not the current one.
-  auto retire = [&](Pass ps) -> cc_status {
-    for (;;) {
-      CC_HIP(hipEventSynchronize(d->pass_done[ps.slot]));
-      const int raw = d->h_counts[2 * ps.slot], kept = d->h_counts[2 * ps.slot + 1];
-      if (raw > ps.cap || ps.gen != list_gen) {
-        CC_HIP(hipStreamSynchronize(d->stream));
-        if (raw > d->cand_cap) {
-          d->cand_cap = raw + raw / 2;
-          d->d_cands.release();
-          d->d_out[0].release();
-          d->d_out[1].release();
-          list_gen++;
-        }
-        cc_status st2 = run_device_pass(d, P, ps.dptr, ps.nf, ps.rs, ps.fs, debug, ps.slot);
-        if (st2 != CC_OK) return st2;
-        ps.cap = d->cand_cap;
-        ps.gen = list_gen;
-        CC_HIP(hipMemcpyAsync(d->h_counts + 2 * ps.slot, d->d_counts[ps.slot].p, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
-        CC_HIP(hipEventRecord(d->pass_done[ps.slot], d->stream));
-        continue;
-      }
-      got.resize((size_t)kept);
-      if (kept > 0) {  // the copy stream is free to run while the main stream executes the next pass
-        CC_HIP(hipMemcpyAsync(got.data(), d->d_out[ps.slot].p, (size_t)kept * sizeof(CandOut), hipMemcpyDeviceToHost, d->copy_stream));
-        CC_HIP(hipStreamSynchronize(d->copy_stream));
-        for (CandOut& c : got) c.frame += ps.f0;
-      }
-      consume(ps.f0, ps.nf, got);
-      return CC_OK;
-    }
-  };
-  Pass prev{};
-  bool have_prev = false;
-  int slot = 0;
+  // spec_poll may have installed another kernel: a pending pass keeps the results it was launched for, nothing to redo.
   int f0 = 0;
   for (size_t pi = 0; pi < sizes.size(); f0 += sizes[pi], pi++) {
-    Pass ps;
+    const int slot = d->next_slot;
+    cc_detector::PendingPass ps;
+    ps.plan = P;
     ps.f0 = f0;
     ps.nf = sizes[pi];
     ps.slot = slot;
     ps.rs = row_stride;
     ps.fs = frame_stride;
+    ps.debug = debug;
+    ps.sink = sink;
     if (on_device) {
       ps.dptr = frames + (size_t)f0 * frame_stride;
     } else {  // staging area is double-buffered like the results
@@ -2264,25 +2326,34 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
                                 (size_t)width, (size_t)height, hipMemcpyHostToDevice, front));
       ps.dptr = stage;
     }
+    // the slot's result buffers are free: the pass that used them last was retired when the pass after it was launched
     stt = run_device_pass(d, P, ps.dptr, ps.nf, ps.rs, ps.fs, debug, slot);
     if (stt != CC_OK) return stt;
     ps.cap = d->cand_cap;
-    ps.gen = list_gen;
+    ps.gen = d->list_gen;
     if (want_results) {
       CC_HIP(hipMemcpyAsync(d->h_counts + 2 * slot, d->d_counts[slot].p, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
       CC_HIP(hipEventRecord(d->pass_done[slot], d->stream));
-      if (have_prev) {
-        stt = retire(prev);
-        if (stt != CC_OK) return stt;
+      // fetch the pass launched before this one -- of this batch or, for the first pass, of the batch submitted before --
+      // while the device runs this one
+      if (d->pending.active) {
+        if (d->pending.sink == sink) {
+          stt = retire_pending(d);
+          if (stt != CC_OK) return stt;
+        } else
+          retire_foreign(d);
       }
-      prev = ps;
-      have_prev = true;
+      ps.active = true;
+      d->pending = ps;
     }
-    slot ^= 1;
+    d->next_slot ^= 1;
   }
-  if (have_prev) {
-    stt = retire(prev);
-    if (stt != CC_OK) return stt;
+  if (d->pending.active && !(defer_last && d->pending.sink == sink)) {
+    if (d->pending.sink == sink) {
+      stt = retire_pending(d);
+      if (stt != CC_OK) return stt;
+    } else
+      retire_foreign(d);
   }
   if (d->profiling) {
     CC_HIP(hipStreamSynchronize(d->stream));
@@ -2300,6 +2371,30 @@ static void sort_candidates(std::vector<CandOut>& v) {
   });
 }
 
+
+// Host side of one pass (called while the device already runs the next pass). Per frame: order the candidates (scale, y, x)
+// = OpenCV's single-threaded order, then group. Frames are independent, so they are spread over a few host threads.
+static void group_pass(int min_neighbors, int f0, int nf, std::vector<CandOut>& cands, std::vector<std::vector<cc_rect>>& grouped) {
+  std::vector<std::vector<CandOut>> per_frame((size_t)nf);
+  for (const CandOut& c : cands) per_frame[(size_t)(c.frame - f0)].push_back(c);
+  auto work = [&](int a0, int a1) {
+    for (int f = a0; f < a1; f++) {
+      sort_candidates(per_frame[(size_t)f]);
+      std::vector<cc_rect>& rects = grouped[(size_t)(f0 + f)];
+      rects.reserve(per_frame[(size_t)f].size());
+      for (const CandOut& c : per_frame[(size_t)f]) rects.push_back(cc_rect{c.x, c.y, c.w, c.h});
+      group_rectangles(rects, min_neighbors, 0.2);  // GROUP_EPS
+    }
+  };
+  const int nthr = std::max(1, std::min({nf, (int)std::thread::hardware_concurrency(), 16}));
+  if (nthr <= 1 || cands.size() < 2048)
+    work(0, nf);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthr; t++) th.emplace_back(work, (int)((long long)nf * t / nthr), (int)((long long)nf * (t + 1) / nthr));
+    for (auto& t : th) t.join();
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Run-time specialisation of the cascade kernel (hiprtc, loaded on demand: the library does not link against it).
@@ -2758,6 +2853,11 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
 void cc_detector_destroy(cc_detector* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
+  if (d->pending.active) {  // a submitted batch nobody collected: let the device finish, drop the results
+    (void)hipStreamSynchronize(d->stream);
+    d->pending.active = false;
+    d->pending.sink.reset();
+  }
   delete d;
 }
 
@@ -2850,30 +2950,11 @@ cc_status cc_detect_batch(cc_detector* d, const uint8_t* frames, int on_device, 
   double group_ms = 0;
   size_t n_cands = 0;
   std::vector<std::vector<cc_rect>> grouped((size_t)n_frames);
-  // Called once per pass, while the device already runs the next pass. Per frame: order candidates (scale, y, x) =
-  // OpenCV's single-threaded order, then group. Frames are independent, so they are spread over a few host threads.
+  const int min_neighbors = p->min_neighbors;
   auto consume = [&](int f0, int nf, std::vector<CandOut>& cands) {
     const auto t0 = std::chrono::steady_clock::now();
     n_cands += cands.size();
-    std::vector<std::vector<CandOut>> per_frame((size_t)nf);
-    for (const CandOut& c : cands) per_frame[(size_t)(c.frame - f0)].push_back(c);
-    auto work = [&](int a0, int a1) {
-      for (int f = a0; f < a1; f++) {
-        sort_candidates(per_frame[(size_t)f]);
-        std::vector<cc_rect>& rects = grouped[(size_t)(f0 + f)];
-        rects.reserve(per_frame[(size_t)f].size());
-        for (const CandOut& c : per_frame[(size_t)f]) rects.push_back(cc_rect{c.x, c.y, c.w, c.h});
-        group_rectangles(rects, p->min_neighbors, 0.2);  // GROUP_EPS
-      }
-    };
-    const int nthr = std::max(1, std::min({nf, (int)std::thread::hardware_concurrency(), 16}));
-    if (nthr <= 1 || cands.size() < 2048)
-      work(0, nf);
-    else {
-      std::vector<std::thread> th;
-      for (int t = 0; t < nthr; t++) th.emplace_back(work, (int)((long long)nf * t / nthr), (int)((long long)nf * (t + 1) / nthr));
-      for (auto& t : th) t.join();
-    }
+    group_pass(min_neighbors, f0, nf, cands, grouped);
     group_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
   st = run_batch(d, frames, on_device, n_frames, width, height, row_stride, frame_stride, p, true, false, consume);
@@ -2893,6 +2974,71 @@ cc_status cc_detect_batch(cc_detector* d, const uint8_t* frames, int on_device, 
                  std::chrono::duration<double, std::milli>(t1 - t_start).count(), group_ms, n_cands);
   }
   if (total > cap) return set_error(CC_ERR_BUFFER_TOO_SMALL, "cc_detect_batch: %lld rectangles, capacity %d", total, cap);
+  return CC_OK;
+}
+
+struct cc_batch_ticket {
+  cc_detector* owner = nullptr;
+  int n_frames = 0;
+  std::shared_ptr<BatchSink> sink;
+  std::vector<std::vector<cc_rect>> grouped;
+};
+
+cc_status cc_detect_batch_submit(cc_detector* d, const uint8_t* frames, int on_device, int n_frames, int width, int height,
+                                 size_t row_stride, size_t frame_stride, const cc_detect_params* p, cc_batch_ticket** ticket) {
+  if (!ticket) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch_submit: null ticket pointer");
+  *ticket = nullptr;
+  cc_status st = check_frame_args(d, frames, n_frames, width, height, row_stride, p, "cc_detect_batch_submit");
+  if (st != CC_OK) return st;
+  std::unique_ptr<cc_batch_ticket> t(new cc_batch_ticket);
+  t->owner = d;
+  t->n_frames = n_frames;
+  t->grouped.resize((size_t)n_frames);
+  t->sink = std::make_shared<BatchSink>();
+  cc_batch_ticket* raw = t.get();
+  const int min_neighbors = p->min_neighbors;
+  t->sink->consume = [raw, min_neighbors](int f0, int nf, std::vector<CandOut>& cands) { group_pass(min_neighbors, f0, nf, cands, raw->grouped); };
+  st = run_batch(d, frames, on_device, n_frames, width, height, row_stride, frame_stride, p, true, false,
+                 [](int, int, std::vector<CandOut>&) {}, /*defer_last=*/true, t->sink);
+  if (st != CC_OK) {
+    if (d->pending.active && d->pending.sink == t->sink) {  // nothing may refer to the ticket once it is gone
+      d->pending.active = false;
+      d->pending.sink.reset();
+    }
+    return st;
+  }
+  *ticket = t.release();
+  return CC_OK;
+}
+
+cc_status cc_detect_batch_collect(cc_detector* d, cc_batch_ticket* t, cc_rect* out, int cap, int32_t* offsets) {
+  if (!t) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch_collect: null ticket");
+  std::unique_ptr<cc_batch_ticket> own(t);  // the ticket ends here, whatever happens
+  if (!d || t->owner != d) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch_collect: the ticket belongs to another detector");
+  if (!offsets || (cap > 0 && !out) || cap < 0) {
+    if (d->pending.active && d->pending.sink == t->sink) (void)retire_pending(d);
+    return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch_collect: bad output buffers");
+  }
+  cc_status st = ensure_device(d->device);
+  if (st != CC_OK) return st;
+  if (d->pending.active && d->pending.sink == t->sink) {  // its last pass has not been fetched by a later submit
+    st = retire_pending(d);
+    if (st != CC_OK) return st;
+  }
+  if (t->sink->status != CC_OK) return set_error(t->sink->status, "cc_detect_batch_collect: %s", t->sink->error.c_str());
+  long long total = 0;
+  for (int f = 0; f < t->n_frames; f++) {
+    offsets[f] = (int32_t)total;
+    for (const cc_rect& r : t->grouped[(size_t)f]) {
+      if (total < cap) out[total] = r;
+      total++;
+    }
+  }
+  offsets[t->n_frames] = (int32_t)total;
+  if (total > cap) {
+    (void)own.release();  // the results stay in the ticket: collect again with room for offsets[n_frames] rectangles
+    return set_error(CC_ERR_BUFFER_TOO_SMALL, "cc_detect_batch_collect: %lld rectangles, capacity %d", total, cap);
+  }
   return CC_OK;
 }
 

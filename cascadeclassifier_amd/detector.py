@@ -202,6 +202,42 @@ class CascadeClassifier:
             L.check(st)
             return [out[offs[i]:offs[i + 1]].copy() for i in range(n)]
 
+    def detect_batch_submit(self, frames, scaleFactor=1.1, minNeighbors=3, minSize=None, maxSize=None, device_ptr=None,
+                            shape=None, row_stride=None, frame_stride=None):
+        """First half of detect_batch (cc_detect_batch_submit): launches the batch and returns a ticket while its last pass
+        still runs. Submit the next batch before collecting this one to overlap them. The frames must stay alive until
+        detect_batch_collect(ticket)."""
+        p = _params(scaleFactor, minNeighbors, minSize, maxSize)
+        keep = None
+        if device_ptr is None:
+            keep = frames = np.ascontiguousarray(frames, np.uint8)
+            n, h, w = frames.shape
+            ptr, on_dev, rs, fs = _vp(frames), 0, w, w * h
+        else:
+            n, h, w = shape
+            ptr, on_dev = C.c_void_p(device_ptr), 1
+            rs = row_stride or w
+            fs = frame_stride or rs * h
+        t = C.c_void_p()
+        L.check(L.lib().cc_detect_batch_submit(self._detector(), ptr, on_dev, n, w, h, rs, fs, C.byref(p), C.byref(t)))
+        return {"ticket": t, "n": n, "frames": keep}
+
+    def detect_batch_collect(self, ticket):
+        """Second half: waits for the batch and returns what detect_batch returns (a list of (k_i, 4) arrays)."""
+        n = ticket["n"]
+        cap = max(256 * n, 1024)
+        while True:
+            out = np.zeros((cap, 4), np.int32)
+            offs = np.zeros(n + 1, np.int32)
+            st = L.lib().cc_detect_batch_collect(self._detector(), ticket["ticket"], _vp(out), cap, _vp(offs))
+            if st == L.CC_ERR_BUFFER_TOO_SMALL:  # the ticket is still valid
+                cap = int(offs[n])
+                continue
+            ticket["ticket"] = None
+            ticket["frames"] = None
+            L.check(st)
+            return [out[offs[i]:offs[i + 1]].copy() for i in range(n)]
+
     def run_device_only(self, device_ptr, shape, scaleFactor=1.1, minSize=None, maxSize=None, row_stride=None,
                         frame_stride=None):
         n, h, w = shape

@@ -235,3 +235,49 @@ def test_single_image_calls_run_from_a_hipgraph(haar_xml, monkeypatch, capfd):
         assert not q.graph_active()
         assert r.shape == want.shape and (r == want).all()
     assert capfd.readouterr().err.count("hipGraph capture of the single-image pass failed") == 1
+
+
+def test_submit_collect_pipelines_batches_with_identical_results(haar_xml, lbp_xml, monkeypatch):
+    """cc_detect_batch_submit / cc_detect_batch_collect: batches submitted back to back (the next one before the previous
+    one is collected) return exactly what detect_batch returns, whatever else happens in between: another plan (other
+    frame size), a single-image call (hipGraph path), a debug call, host and device frames, an overflowing candidate list."""
+    import torch
+    p = cc.CascadeClassifier(haar_xml, max_batch=8)
+    p.specialize(4)
+    a = np.stack([frame_natural(480, 270, 100 + i) for i in range(7)])
+    b = np.stack([frame_natural(480, 270, 200 + i) for i in range(5)])
+    c = np.stack([frame_natural(320, 200, 300 + i) for i in range(3)])  # another plan
+    want = {k: p.detect_batch(v, 1.1, 2) for k, v in (("a", a), ("b", b), ("c", c))}
+    da = torch.from_numpy(a).cuda()
+
+    def same(got, key):
+        assert len(got) == len(want[key]) and all(x.shape == y.shape and (x == y).all() for x, y in zip(got, want[key]))
+    t1 = p.detect_batch_submit(a, 1.1, 2)
+    t2 = p.detect_batch_submit(b, 1.1, 2)          # fetches t1's last pass while b's first pass runs
+    same(p.detect_batch_collect(t1), "a")
+    t3 = p.detect_batch_submit(None, 1.1, 2, device_ptr=da.data_ptr(), shape=a.shape)
+    same(p.detect_batch_collect(t2), "b")
+    t4 = p.detect_batch_submit(c, 1.1, 2)          # other frame size: t3's pending pass is fetched first
+    one = p.detectMultiScale(a[0], 1.1, 2)         # single-image call in between (flushes t4's pending pass)
+    assert one.shape == want["a"][0].shape and (one == want["a"][0]).all()
+    same(p.detect_batch_collect(t4), "c")
+    same(p.detect_batch_collect(t3), "a")          # collected out of order
+    t5 = p.detect_batch_submit(b, 1.1, 2)
+    p.debug_windows(a[1], 1.1)                     # a debug call with a batch pending
+    same(p.detect_batch_collect(t5), "b")
+    same(p.detect_batch(a, 1.1, 2), "a")           # the synchronous call still works afterwards
+    # overflowing candidate lists (tiny initial capacity) while batches overlap
+    monkeypatch.setenv("CCAMD_CAND_CAP", "16")
+    q = cc.CascadeClassifier(haar_xml, max_batch=8)
+    t6 = q.detect_batch_submit(a, 1.1, 2)
+    t7 = q.detect_batch_submit(b, 1.1, 2)
+    same(q.detect_batch_collect(t6), "a")
+    same(q.detect_batch_collect(t7), "b")
+    # LBP (wave phase, 16-bit tiles) through the same path
+    r = cc.CascadeClassifier(lbp_xml, max_batch=8)
+    r.specialize(20)
+    wl = r.detect_batch(a, 1.1, 2)
+    t8, t9 = r.detect_batch_submit(a, 1.1, 2), r.detect_batch_submit(a, 1.1, 2)
+    for t in (t8, t9):
+        got = r.detect_batch_collect(t)
+        assert all(x.shape == y.shape and (x == y).all() for x, y in zip(got, wl))
