@@ -917,7 +917,7 @@ struct cc_detector {
   uint8_t* h_frame = nullptr;  // pinned staging copy of a single host image (graph path)
   size_t h_frame_bytes = 0;
   int use_graph = 1;
-  int early_skip = 1, full_sqsum = 0, pipeline_passes = 4, even_passes = 0;  // tuning knobs, read once at creation
+  int early_skip = 1, full_sqsum = 0, pipeline_passes = 4, pipeline_passes_set = 0, even_passes = 0;  // tuning knobs, read once at creation
   hipStream_t copy_stream = nullptr;
   hipEvent_t pass_done[2] = {nullptr, nullptr};
   int cand_cap = 0;
@@ -2284,10 +2284,13 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
   // Pass sizes. With results wanted the batch is cut into a few passes so that the host side of pass i (copy-back +
   // grouping) overlaps the device side of pass i+1 and the pyramid/integrals of pass i+1 overlap the cascade kernel of
   // pass i. Nothing overlaps the LAST pass's host work, so it carries about half the frames of the others (32 frames ->
-  // 9, 9, 9, 5; a small first pass, to start the cascade kernel earlier, measured no better).
+  // 9, 9, 9, 5; a small first pass, to start the cascade kernel earlier, measured no better). A SUBMITTED batch has its last
+  // pass overlapped by the batch after it, so it is cut into two even passes only (bench step 17.51 ms against 17.86 / 18.25
+  // for 1 / 4 passes, profiles/r03_kernel_experiments.txt).
   std::vector<int> sizes;
   if (want_results && n_frames >= 2) {
-    const int passes = std::min(d->pipeline_passes, n_frames);
+    const bool submitted = defer_last && !d->pipeline_passes_set;
+    const int passes = std::min(submitted ? 2 : d->pipeline_passes, n_frames);
     const char* explicit_sizes = std::getenv("CCAMD_PASS_SIZES");  // tuning: comma-separated sizes
     if (explicit_sizes && *explicit_sizes) {
       for (const char* q = explicit_sizes; *q;) {
@@ -2298,7 +2301,7 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
       }
     } else {
       int per = (n_frames + passes - 1) / passes;
-      if (passes >= 3 && !d->even_passes) {
+      if (passes >= 3 && !d->even_passes && !submitted) {
         const int big = (2 * n_frames + 2 * passes - 2) / (2 * passes - 1);
         if (big >= 2 && big * (passes - 1) < n_frames) per = big;
       }
@@ -2381,8 +2384,13 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     } else
       retire_foreign(d);
   }
-  if (d->profiling) {
+  // Profiling: the event pairs of this call are read once their kernels are done. A submitted batch must not wait for that
+  // here (the synchronisation would undo the overlap with the next batch -- which is how the round-3 bench first measured
+  // its own instrumentation instead of the pipeline): its events are read by cc_detector_get_timings or by the next
+  // synchronous call.
+  if (d->profiling && !defer_last) {
     CC_HIP(hipStreamSynchronize(d->stream));
+    if (d->front_stream) CC_HIP(hipStreamSynchronize(d->front_stream));
     collect_events(d);
   }
   return CC_OK;
@@ -2764,7 +2772,10 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   if (const char* e = std::getenv("CCAMD_DEBUG_STOP_AFTER_STAGE")) d->stop_after = std::atoi(e);  // timing experiments
   d->early_skip = std::getenv("CCAMD_NO_EARLY_SKIP") ? 0 : 1;
   d->full_sqsum = std::getenv("CCAMD_FULL_SQSUM") ? 1 : 0;
-  if (const char* e = std::getenv("CCAMD_PIPELINE_PASSES")) d->pipeline_passes = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("CCAMD_PIPELINE_PASSES")) {
+    d->pipeline_passes = std::max(1, std::atoi(e));
+    d->pipeline_passes_set = 1;
+  }
   if (const char* e = std::getenv("CCAMD_CAND_CAP")) d->cand_cap = std::max(16, std::atoi(e));  // initial candidate-list capacity (tests: forces the overflow path)
   d->even_passes = std::getenv("CCAMD_EVEN_PASSES") ? 1 : 0;
   if (const char* e = std::getenv("CCAMD_DEBUG_EXTRA_LDS")) {  // occupancy experiments: pad the per-block LDS request
@@ -2953,6 +2964,13 @@ cc_status cc_detector_set_profiling(cc_detector* d, int enabled) {
 
 cc_status cc_detector_get_timings(cc_detector* d, cc_detector_timings* t, int reset) {
   if (!d || !t) return set_error(CC_ERR_INVALID_ARG, "cc_detector_get_timings: null argument");
+  if (!d->events.empty()) {  // event pairs of submitted batches: their kernels may still be running
+    cc_status st = ensure_device(d->device);
+    if (st != CC_OK) return st;
+    CC_HIP(hipStreamSynchronize(d->stream));
+    if (d->front_stream) CC_HIP(hipStreamSynchronize(d->front_stream));
+    collect_events(d);
+  }
   *t = d->tm;
   if (reset) std::memset(&d->tm, 0, sizeof(d->tm));
   return CC_OK;

@@ -193,9 +193,20 @@ int main() {
   mk("all lanes one bank (32*lane)", [](int k, int l) { return k + 32 * l; });
   mk("pairs: 2*lane (b64 natural)", [](int k, int l) { return k * 200 + 2 * l; });
   mk("scattered, banks distinct per half", [](int k, int l) { return ((l * 7 + k * 3) % 32) + 32 * ((l * 13 + k) % 150); });
-  for (int mode = 0; mode < 5; mode++)
-    for (auto& p : pats)
+  const size_t n_common = pats.size();
+  // ds_read_b64 at 4-byte granularity (mode 5: addresses as given, not rounded to 8 bytes): window pairs in one LDS plane
+  mk("b64 pairs aligned (2*lane)", [](int k, int l) { return k * 200 + 2 * l; });
+  mk("b64 pairs misaligned (2*lane+1)", [](int k, int l) { return k * 200 + 2 * l + 1; });
+  mk("b64 mixed alignment (2*lane+(lane/7&1))", [](int k, int l) { return k * 200 + 2 * l + ((l / 7) & 1); });
+  mk("b64 scattered, 8-byte banks distinct", [](int k, int l) { return 2 * ((l * 7 + k * 3) % 32) + 64 * ((l * 13 + k) % 75); });
+  mk("b64 scattered, distinct, misaligned", [](int k, int l) { return 2 * ((l * 7 + k * 3) % 32) + 64 * ((l * 13 + k) % 75) + 1; });
+  mk("b64 scattered, 4-byte class per half", [](int k, int l) { return ((l * 7 + k * 3) % 32) + 32 * ((l * 13 + k) % 150); });
+  mk("b64 consecutive words (overlap)", [](int k, int l) { return k * 200 + l; });
+  for (int mode = 0; mode < 6; mode++)
+    for (size_t pi = 0; pi < pats.size(); pi++)
       for (int wps : {1, 4}) {
+        const Pat& p = pats[pi];
+        if ((mode == 5) != (pi >= n_common)) continue;
         std::vector<int> w = p.w;
         if (mode == 2)
           for (auto& x : w) x &= ~1;
@@ -207,12 +218,13 @@ int main() {
           if (mode == 2) hipLaunchKernelGGL(k_lds<2>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
           if (mode == 3) hipLaunchKernelGGL(k_lds<3>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
           if (mode == 4) hipLaunchKernelGGL(k_lds<4>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
+          if (mode == 5) hipLaunchKernelGGL(k_lds<2>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
         }
         CK(hipDeviceSynchronize());
         const double cyc = median_cycles(d_out, blocks);
         const double n_instr = (double)ITER * (mode == 1 ? 4 : 8) * wps * 4;  // wave-instructions per CU
-        const char* mname[] = {"ds_read_b32", "ds_read2_b32", "ds_read_b64", "ds_read_u16", "ds_read_u16_d16(+hi)"};
-        const double bytes_per_instr[] = {256.0, 512.0, 512.0, 128.0, 128.0};
+        const char* mname[] = {"ds_read_b32", "ds_read2_b32", "ds_read_b64", "ds_read_u16", "ds_read_u16_d16(+hi)", "ds_read_b64 (4B addr)"};
+        const double bytes_per_instr[] = {256.0, 512.0, 512.0, 128.0, 128.0, 512.0};
         printf("LDS %-20s %-32s waves/CU=%2d : %.2f cycles per wave-instruction per CU (%.1f B/clk/CU)\n", mname[mode], p.name, wps * 4,
                cyc / n_instr, bytes_per_instr[mode] / (cyc / n_instr));
       }
