@@ -882,7 +882,8 @@ struct cc_detector {
   size_t lds = 0;  // dynamic LDS bytes per tile (larger of the two layouts)
   size_t lds_spec = 0;  // the same for the installed specialised kernel (smaller when its STEP-2 tiles hold 16-bit entries)
   size_t lds_extra = 0; // CCAMD_DEBUG_EXTRA_LDS (occupancy experiments)
-  int spec_tile16 = 0;
+  int spec_tmode = 0;  // TILE_32 / TILE_16 / TILE_PAIR16 of the installed specialised kernel
+  DevBuf<HaarStumpP16> d_haar_p16, d_haar_p16w;  // table-driven stumps of the pair tile: stage order, wave-phase order
   // plans + workspace
   std::vector<std::unique_ptr<Plan>> plans;
   DevBuf<uint8_t> d_frames, d_pyr;
@@ -903,7 +904,7 @@ struct cc_detector {
   std::atomic<int> spec_bg_state{0};  // 0 idle, 1 building, 2 ready to install, 3 failed
   std::vector<char> spec_bg_code;
   int spec_bg_stages = 0;
-  bool spec_bg_tile16 = false;
+  int spec_bg_tmode = 0;
   std::string spec_bg_error;
   // Per slot, like the results. (Round 3 also ran the cascade kernels of consecutive passes on two streams, so that the next
   // one starts on the CUs the previous one's last blocks leave free: 18.50 -> 19.24 ms per step, two kernels of this size
@@ -1060,6 +1061,7 @@ static void build_haar_stumps_at(const Cascade& m, std::vector<HaarStumpDev>& ou
     d.thr = m.stump_threshold[i];
     d.left = m.stump_left[i];
     d.right = m.stump_right[i];
+    d.pad = (int)i;  // the stump's index: survives the re-ordering of schedule_for_wave_phase
   }
 }
 template <int STEP>
@@ -1158,6 +1160,10 @@ template <int STEP>
 static void build_lbp_stumps(const Cascade& m, std::vector<LbpStumpDev>& out);
 static void build_lbp_stumps16(const Cascade& m, std::vector<LbpStumpDev>& out);
 
+// Layout of the STEP-2 tiles of a specialised kernel: 32-bit entries in two column planes (TileGeom<2>), 16-bit entries
+// (TileGeom16), or packed pairs of 16-bit entries (TileGeomP: two neighbouring windows per LDS read, Haar stumps).
+enum { TILE_32 = 0, TILE_16 = 1, TILE_PAIR16 = 2 };
+
 // A rectangle sum read from 16-bit entries is exact when 255 * area < 2^16.
 static bool fits16(long long area) { return 255LL * area <= 65535LL; }
 
@@ -1209,9 +1215,65 @@ static bool tile16_eligible(const Cascade& m, int n_stages) {
   return true;
 }
 
-static std::string spec_stage_source(const Cascade& m, int n_stages, bool tile16) {
+// Table-driven records of the pair tile: every rectangle as strips whose sums fit 16 bits. False when a stump needs more
+// than P16_PIECES pieces or an offset does not fit the record.
+static bool build_haar_stumps_p16(const Cascade& m, std::vector<HaarStumpP16>& out) {
+  const TileGeomP G(m.win_w, m.win_h);
+  out.assign(m.stump_feature.size(), HaarStumpP16{});
+  for (size_t i = 0; i < out.size(); i++) {
+    HaarStumpP16& d = out[i];
+    std::memset(&d, 0, sizeof(d));
+    const int fi = m.stump_feature[i];
+    if (m.haar_tilted[(size_t)fi]) return false;
+    d.nrect = 2;
+    int np = 0;
+    for (int j = 0; j < 3; j++) {
+      const int32_t* r = &m.haar_rects[(size_t)fi * 12 + j * 4];
+      const float wt = m.haar_weights[(size_t)fi * 3 + j];
+      d.w[j] = wt;
+      const bool used = j < 2 || wt != 0.0f;
+      if (j == 2 && wt != 0.0f) d.nrect = 3;
+      if (!used || r[2] <= 0 || r[3] <= 0) continue;  // an empty rectangle sums to 0: no piece
+      const auto pcs = pieces16(r[0], r[1], r[2], r[3]);
+      if (pcs.empty()) return false;
+      for (const auto& pc : pcs) {
+        if (np >= P16_PIECES) return false;
+        const int o4[4] = {G.at(pc[1], pc[0]), G.at(pc[1], pc[0] + pc[2]), G.at(pc[1] + pc[3], pc[0]), G.at(pc[1] + pc[3], pc[0] + pc[2])};
+        for (int k = 0; k < 4; k++) {
+          if (o4[k] < 0 || o4[k] > 65535) return false;
+          d.ofs[np][k] = (unsigned short)o4[k];
+        }
+        d.rect_of[np++] = (unsigned char)j;
+      }
+    }
+    d.npieces = (unsigned char)np;
+    d.thr = m.stump_threshold[i];
+    d.left = m.stump_left[i];
+    d.right = m.stump_right[i];
+  }
+  return true;
+}
+
+// Can the specialised kernel use the pair tile (TileGeomP) for its STEP-2 tiles? Upright Haar stump cascades whose
+// variance rectangle splits into two halves that fit 16 bits, whose every stump fits the pair tile's record, and whose
+// tile row fits one wavefront of 4-column groups (stage_tile_pair). CCAMD_SPEC_PAIR16=0 / 1 turns it off / on.
+static bool pair16_eligible(const Cascade& m) {
+  if (m.feature_type != CC_FEATURE_HAAR || m.max_nodes_per_tree > 1 || m.has_tilted) return false;
+  const char* on = std::getenv("CCAMD_SPEC_PAIR16");
+  if (!(on && std::atoi(on) != 0)) return false;
+  if (TILE_Y != 2 * EVAL_WAVES || TILE_X != 64) return false;
+  const int nrx = m.win_w - 2, nry = m.win_h - 2;
+  if (nrx < 2 || !fits16((long long)(nrx - (nrx >> 1)) * nry)) return false;
+  if (!fits16(std::max(m.win_w, m.win_h))) return false;
+  const TileGeomP G(m.win_w, m.win_h);
+  if ((G.cols + 3) / 4 > 64) return false;
+  std::vector<HaarStumpP16> tmp;
+  return build_haar_stumps_p16(m, tmp);
+}
+
+static std::string spec_stage_source(const Cascade& m, int n_stages, int tmode) {
   const CNumericLocale c_numbers;  // "%a" literals must not follow the host program's LC_NUMERIC
-  if (m.feature_type == CC_FEATURE_LBP) return spec_stage_source_lbp(m, n_stages, tile16);
+  if (m.feature_type == CC_FEATURE_LBP) return spec_stage_source_lbp(m, n_stages, tmode == TILE_16);
   std::vector<HaarStumpDev> t[2];
   build_haar_stumps<1>(m, t[0]);
   build_haar_stumps<2>(m, t[1]);
@@ -1259,6 +1321,8 @@ static std::string spec_stage_source(const Cascade& m, int n_stages, bool tile16
     q = std::ldexp(1.0, emin - 24);  // every leaf is a multiple of q (see stage_sums_order_independent)
     return mag / q < 2147483647.0;
   };
+  std::function<std::string(const HaarStumpDev&, const std::string&, double, SpecStump&)> vote_text;
+  const TileGeomP GP(m.win_w, m.win_h);
   auto stump = [&](const HaarStumpDev& d, int stump_index, int local, const std::string& win, double fixed_q, bool h16) {
     const int fi = m.stump_feature[(size_t)stump_index];
     const std::string tile_ptr = (h16 ? "h" : "b") + win;  // h<win>: the same tile base as 16-bit entries
@@ -1404,6 +1468,12 @@ static std::string spec_stage_source(const Cascade& m, int n_stages, bool tile16
         out.compute = e2 + "; v *= vnf" + win + "; asm volatile(\"\" :: \"v\"(v)); } ";
       }
     }
+    out.compute += e + vote_text(d, win, fixed_q, out);
+    return out;
+  };
+  // Text that follows a stump's value expression "{ float v = ...": normalisation and the vote into the accumulator of
+  // window `win` (closes the brace); records the constant part of a delta-form vote in `out`.
+  vote_text = [&](const HaarStumpDev& d, const std::string& win, double fixed_q, SpecStump& out) -> std::string {
     if (delta_form && fixed_q > 0.) {
       char delta[64];
       const long long lq = (long long)std::llround((double)d.left / fixed_q), rq = (long long)std::llround((double)d.right / fixed_q);
@@ -1427,23 +1497,147 @@ static std::string spec_stage_source(const Cascade& m, int n_stages, bool tile16
       } else
       snprintf(vote, sizeof(vote), "; v *= vnf%s; { unsigned dq; asm volatile(\"v_mov_b32_e32 %%0, %s\" : \"=v\"(dq)); ai%s += (v < %s ? dq : 0u); asm volatile(\"\" : \"+v\"(ai%s)); } }",
                win.c_str(), delta, win.c_str(), hexf(d.thr).c_str(), win.c_str());
-      out.compute += e + vote;
       out.base = (double)d.right;
       out.base_q = rq;
-    } else if (delta_form) {  // vote = right + (v < thr ? left - right : 0): the constant `right` is added once per part
+      return vote;
+    }
+    if (delta_form) {  // vote = right + (v < thr ? left - right : 0): the constant `right` is added once per part
       char delta[64];  // (hexf reuses `buf`)
       snprintf(delta, sizeof(delta), "%a", (double)d.left - (double)d.right);
-      out.compute += e + "; v *= vnf" + win + "; acc" + win + " += (v < " + hexf(d.thr) + " ? " + delta + " : 0.); }";
       out.base = (double)d.right;
-    } else
-      out.compute += e + "; v *= vnf" + win + "; acc" + win + " += (double)(v < " + hexf(d.thr) + " ? " + hexf(d.left) + " : " + hexf(d.right) + "); }";
+      return "; v *= vnf" + win + "; acc" + win + " += (v < " + hexf(d.thr) + " ? " + delta + " : 0.); }";
+    }
+    return "; v *= vnf" + win + "; acc" + win + " += (double)(v < " + hexf(d.thr) + " ? " + hexf(d.left) + " : " + hexf(d.right) + "); }";
+  };
+  // One stump for the two windows of a pair-tile slot (TileGeomP): every corner word is read once and holds both windows'
+  // entries, the corner combinations are packed 16-bit arithmetic, the two halves then go their own way (conversion,
+  // normalisation, vote) into acca / accb. Same cases as the 16-bit tile above.
+  auto stump_pair = [&](int stump_index, int local, double fixed_q) {
+    const HaarStumpDev& d = t[1][(size_t)stump_index];
+    const int fi = m.stump_feature[(size_t)stump_index];
+    bool int_ok = true;
+    double bound = 0;
+    for (int j = 0; j < d.nrect; j++) {
+      const float w = d.w[j];
+      const int32_t* r = &m.haar_rects[(size_t)fi * 12 + j * 4];
+      if (w != std::nearbyint(w) || std::fabs(w) > 64.f) int_ok = false;
+      bound += std::fabs((double)w) * 255.0 * (double)r[2] * (double)r[3];
+    }
+    if (bound >= 16777216.0) int_ok = false;
+    SpecStump out;
+    std::map<int, std::string> var;
+    auto var_of = [&](int ofs) {
+      auto it = var.find(ofs);
+      if (it != var.end()) return it->second;
+      snprintf(buf, sizeof(buf), "x%d_%d", local, (int)var.size());
+      const std::string name = buf;
+      var[ofs] = name;
+      out.decls += (out.decls.empty() ? "cc_us2 " : ", ") + name;
+      snprintf(buf, sizeof(buf), "%s = cc_pk(b[%d]); ", name.c_str(), ofs);
+      out.loads += buf;
+      return name;
+    };
+    long long vmin = 0, vmax = 0;
+    if (int_ok) {
+      std::vector<int> net((size_t)(m.win_w + 1) * (size_t)(m.win_h + 1), 0);
+      for (int j = 0; j < d.nrect; j++) {
+        const int32_t* r = &m.haar_rects[(size_t)fi * 12 + j * 4];
+        for (int yy = r[1]; yy < r[1] + r[3]; yy++)
+          for (int xx = r[0]; xx < r[0] + r[2]; xx++) net[(size_t)yy * (size_t)(m.win_w + 1) + (size_t)xx] += (int)d.w[j];
+      }
+      for (int v : net) (v > 0 ? vmax : vmin) += 255LL * v;
+    }
+    std::string pre, ea, eb;  // packed part, value of the first / second window
+    if (int_ok && vmin >= -32768 && vmax <= 32767) {
+      std::map<int, int> coef;
+      static const int sign[4] = {1, -1, -1, 1};
+      for (int j = 0; j < d.nrect; j++) {
+        const int32_t* r = &m.haar_rects[(size_t)fi * 12 + j * 4];
+        const int o4[4] = {GP.at(r[1], r[0]), GP.at(r[1], r[0] + r[2]), GP.at(r[1] + r[3], r[0]), GP.at(r[1] + r[3], r[0] + r[2])};
+        for (int k = 0; k < 4; k++) coef[o4[k]] += sign[k] * (int)d.w[j];
+      }
+      std::map<int, std::vector<int>> by_coef;
+      for (auto& kv : coef)
+        if (kv.second) by_coef[std::abs(kv.second)].push_back(kv.second > 0 ? kv.first + 1 : -(kv.first + 1));
+      std::string tt;
+      for (auto& g : by_coef) {
+        std::string grp;
+        for (int so : g.second) {
+          grp += so > 0 ? (grp.empty() ? "" : " + ") : " - ";
+          grp += var_of(std::abs(so) - 1);
+        }
+        if (grp.rfind(" - ", 0) == 0) grp = "cc_k2(0)" + grp;
+        if (g.first == 1)
+          tt += (tt.empty() ? "(" : " + (") + grp + ")";
+        else {
+          snprintf(buf, sizeof(buf), "%scc_k2(%d) * (", tt.empty() ? "" : " + ", g.first);
+          tt += buf + grp + ")";
+        }
+      }
+      if (tt.empty()) tt = "cc_k2(0)";
+      pre = "const cc_us2 t = " + tt + "; ";
+      ea = "(float)(int)(short)t.x";
+      eb = "(float)(int)(short)t.y";
+    } else {
+      std::string ia, ib, fa, fb;
+      int np = 0;
+      for (int j = 0; j < d.nrect; j++) {
+        const int32_t* r = &m.haar_rects[(size_t)fi * 12 + j * 4];
+        std::string ra, rb;
+        for (const auto& pc : pieces16(r[0], r[1], r[2], r[3])) {
+          const std::string a = var_of(GP.at(pc[1], pc[0])), b2 = var_of(GP.at(pc[1], pc[0] + pc[2])), c = var_of(GP.at(pc[1] + pc[3], pc[0])),
+                            dd = var_of(GP.at(pc[1] + pc[3], pc[0] + pc[2]));
+          snprintf(buf, sizeof(buf), "q%d", np++);
+          const std::string q = buf;
+          pre += "const cc_us2 " + q + " = " + a + " - " + b2 + " - " + c + " + " + dd + "; ";
+          ra += std::string(ra.empty() ? "" : " + ") + "(int)" + q + ".x";
+          rb += std::string(rb.empty() ? "" : " + ") + "(int)" + q + ".y";
+        }
+        if (ra.empty()) ra = rb = "0";
+        snprintf(buf, sizeof(buf), "%s%d * (", j ? " + " : "", (int)d.w[j]);
+        ia += buf + ra + ")";
+        ib += buf + rb + ")";
+        fa += std::string(j ? " + " : "") + hexf(d.w[j]) + " * (float)(" + ra + ")";
+        fb += std::string(j ? " + " : "") + hexf(d.w[j]) + " * (float)(" + rb + ")";
+      }
+      ea = int_ok ? "(float)(" + ia + ")" : fa;
+      eb = int_ok ? "(float)(" + ib + ")" : fb;
+    }
+    if (!out.decls.empty()) out.decls += ";";
+    SpecStump other;  // both windows vote with the same constants
+    out.compute = "{ " + pre + "{ float v = " + ea + vote_text(d, "a", fixed_q, out) + " { float v = " + eb + vote_text(d, "b", fixed_q, other) + " }";
     return out;
   };
   for (int step = 1; step <= 2; step++) {
+    if (step == 2 && tmode == TILE_PAIR16) {  // STEP-2 tiles hold window pairs: one function serves the dense and the thread phase
+      snprintf(buf, sizeof(buf),
+               "template <>\n__device__ %s void spec_stage_pair<2>(int st, int p_lo, int p_hi, const int32_t* b, float vnfa, float vnfb, double& "
+               "acc_a, double& acc_b) {\n  double acca = 0., accb = 0.;\n  switch (st) {\n",
+               spec_stage_inline_attr());
+      o += buf;
+      for (int s = 0; s < n_stages; s++) {
+        snprintf(buf, sizeof(buf), "    case %d: {\n", s);
+        o += buf;
+        std::vector<SpecStump> st;
+        double q = 0.;
+        const bool fixed = delta_form && fixed_point_ok && stage_quantum(s, q);
+        for (int i = 0; i < m.stage_ntrees[(size_t)s]; i++) st.push_back(stump_pair(m.stage_first[(size_t)s] + i, i, fixed ? q : 0.));
+        if (fixed) {
+          o += "      unsigned aia = 0u, aib = 0u;\n";
+          spec_emit_stage(o, st, depth, true, {"aia", "aib"}, true);
+          snprintf(buf, sizeof(buf), "      acca = (double)(int)aia * %a;\n      accb = (double)(int)aib * %a;\n", q, q);
+          o += buf;
+        } else
+          spec_emit_stage(o, st, depth, true, {"acca", "accb"});
+        o += "    } break;\n";
+      }
+      o += "    default: break;\n  }\n  acc_a = acca;\n  acc_b = accb;\n}\n";
+      continue;
+    }
     snprintf(buf, sizeof(buf),
              "template <>\n__device__ %s double spec_stage<%d>(int st, int p_lo, int p_hi, const int32_t* b, float vnf) {\n", spec_stage_inline_attr(), step);
     o += buf;
-    const bool h16 = tile16 && step == 2;  // STEP-2 tiles hold 16-bit entries
+    const bool h16 = tmode == TILE_16 && step == 2;  // STEP-2 tiles hold 16-bit entries
     if (h16) o += "  const unsigned short* h = reinterpret_cast<const unsigned short*>(b);\n";
     o += "  double acc = 0.;\n  switch (st) {\n";
     for (int s = 0; s < n_stages; s++) {
@@ -2019,6 +2213,10 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.gstumps = haar ? (const void*)d->d_haar_g.p : (const void*)d->d_lbp_g.p;
     A.lbp16_all = d->lbp16_all;
     if (!haar && d->d_lbp16.p) A.wstumps2 = d->d_lbp16.p;  // LBP wave phase of kernels with 16-bit tiles
+    if (d->spec_fn && d->spec_tmode == TILE_PAIR16) {      // pair tile: its own record format for the table-driven stages
+      A.gstumps = d->d_haar_p16.p;
+      A.wstumps2 = d->d_haar_p16w.p;
+    }
     A.trees = d->m.max_nodes_per_tree > 1 ? 1 : 0;
     A.nodes1 = haar ? (const void*)d->d_hnode1.p : (const void*)d->d_lnode1.p;
     A.nodes2 = haar ? (const void*)d->d_hnode2.p : (const void*)d->d_lnode2.p;
@@ -2474,7 +2672,8 @@ static const char kSpecPrelude[] =
     "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
 
 // Compiles `src` for `arch`; identical (source, options) pairs are served from a per-process cache.
-static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, bool lbp, bool tile16, int win_w, int win_h, std::vector<char>& code) {
+static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, bool lbp, int tmode, int win_w, int win_h, std::vector<char>& code) {
+  const bool tile16 = tmode == TILE_16;
   static std::mutex mu;
   static std::map<std::string, std::vector<char>> cache;
   const std::string o_arch = "--offload-arch=" + arch, o_k = "-DCC_SPEC_STAGES=" + std::to_string(n_stages);
@@ -2487,6 +2686,7 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
   std::vector<const char*> optv = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str(), o_w.c_str(), o_w0.c_str(), o_h0.c_str()};
   if (lbp) optv.push_back("-DCC_SPEC_LBP");
   if (tile16) optv.push_back("-DCC_SPEC_TILE16");
+  if (tmode == TILE_PAIR16) optv.push_back("-DCC_SPEC_PAIR16");
   const char* const* opts = optv.data();
   const int n_opts = (int)optv.size();
   std::string key;  // everything the code object depends on: compiler version, options, then the source
@@ -2612,7 +2812,7 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
 
 // Host half of the specialisation: source for the first stages (whole stages within the code-size budget) compiled for
 // `arch`. No device calls: safe on a background thread.
-static cc_status spec_build(const Cascade& m, int n_stages, const std::string& arch, std::vector<char>& code, int& k_out, bool& tile16_out) {
+static cc_status spec_build(const Cascade& m, int n_stages, const std::string& arch, std::vector<char>& code, int& k_out, int& tmode_out) {
   if (m.max_nodes_per_tree > 1) return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: stump cascades only");
   int k = 0, stumps = 0;
   int budget = 320;  // instruction cache: more stages measured no faster, 12 stages slower
@@ -2626,15 +2826,15 @@ static cc_status spec_build(const Cascade& m, int n_stages, const std::string& a
   const std::string marker = "//@@CC_SPEC_FUNCTIONS@@";
   const size_t pos = src.find(marker);
   if (pos == std::string::npos) return set_error(CC_ERR_HIP, "cc_detector_specialize: kernel source has no specialisation marker");
-  const bool tile16 = tile16_eligible(m, k);
-  src.replace(pos, marker.size(), spec_stage_source(m, k, tile16));
+  const int tmode = pair16_eligible(m) ? TILE_PAIR16 : tile16_eligible(m, k) ? TILE_16 : TILE_32;
+  src.replace(pos, marker.size(), spec_stage_source(m, k, tmode));
   k_out = k;
-  tile16_out = tile16;
-  return compile_specialised(src, arch, k, m.feature_type == CC_FEATURE_LBP, tile16, m.win_w, m.win_h, code);
+  tmode_out = tmode;
+  return compile_specialised(src, arch, k, m.feature_type == CC_FEATURE_LBP, tmode, m.win_w, m.win_h, code);
 }
 
 // Device half: load the code object and make it the detector's cascade kernel. Owning thread only.
-static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int k, bool tile16) {
+static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int k, int tmode) {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   CC_HIP(hipModuleLoadData(&mod, code.data()));
@@ -2643,10 +2843,28 @@ static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int
     return set_error(CC_ERR_HIP, "cc_detector_specialize: entry point not found in the compiled module");
   }
   size_t lds_spec = d->lds;
-  if (tile16) {  // STEP-1 tile in 32 bits, STEP-2 tile in 16 bits
+  if (tmode == TILE_16) {  // STEP-1 tile in 32 bits, STEP-2 tile in 16 bits
     const TileGeom<1> G1(d->m.win_w, d->m.win_h);
     const TileGeom16 G2(d->m.win_w, d->m.win_h);
     lds_spec = eval_lds_bytes(std::max(G1.words(), G2.words()), false) + d->lds_extra;
+  } else if (tmode == TILE_PAIR16) {  // STEP-2 tile of window pairs, with partial sums for both windows of a slot
+    const TileGeom<1> G1(d->m.win_w, d->m.win_h);
+    const TileGeomP G2(d->m.win_w, d->m.win_h);
+    lds_spec = std::max(eval_lds_bytes(G1.words(), false), eval_lds_bytes_pair(G2.words())) + d->lds_extra;
+    if (!d->d_haar_p16.p) {
+      std::vector<HaarStumpP16> tp, tw;
+      build_haar_stumps_p16(d->m, tp);
+      // wave phase: the stage's stumps in the bank-aware order computed for this geometry's offsets (the records carry
+      // their stump's index in `pad`)
+      std::vector<HaarStumpDev> geo;
+      build_haar_stumps_at(d->m, geo, [&](int y, int x) { return G2.at(y, x); }, 0);
+      const std::vector<HaarStumpDev> order = d->wave_below > 0 && !std::getenv("CCAMD_NO_WAVE_SCHEDULE") ? schedule_for_wave_phase(d->m, geo) : geo;
+      tw.reserve(order.size());
+      for (const HaarStumpDev& r : order) tw.push_back(tp[(size_t)r.pad]);
+      CC_HIP(d->d_haar_p16.upload(tp, d->stream));
+      CC_HIP(d->d_haar_p16w.upload(tw, d->stream));
+      CC_HIP(hipStreamSynchronize(d->stream));
+    }
   }
   if (lds_spec > 64 * 1024) {  // same opt-in as the ahead-of-time kernels (cc_detector_create)
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec);
@@ -2657,13 +2875,18 @@ static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int
                        d->lds, hipGetErrorString(e));
     }
   }
+  if (std::getenv("CCAMD_TRACE_HOST")) {  // what the specialised kernel's footprint allows per CU
+    int nb = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, EVAL_THREADS, lds_spec) != hipSuccess) (void)hipGetLastError();
+    std::fprintf(stderr, "[ccamd host] specialised kernel: tile mode %d, %zu bytes of LDS per block, %d resident blocks per CU\n", tmode, lds_spec, nb);
+  }
   CC_HIP(hipStreamSynchronize(d->stream));
   if (d->spec_mod) (void)hipModuleUnload(d->spec_mod);
   d->spec_mod = mod;
   d->spec_fn = fn;
   d->spec_stages = k;
   d->lds_spec = lds_spec;
-  d->spec_tile16 = tile16 ? 1 : 0;
+  d->spec_tmode = tmode;
   return CC_OK;
 }
 
@@ -2680,7 +2903,7 @@ static void spec_poll(cc_detector* d) {
   const int st = d->spec_bg_state.load(std::memory_order_acquire);
   if (st != 2 && st != 3) return;
   if (d->spec_thread.joinable()) d->spec_thread.join();
-  if (st == 2 && spec_install(d, d->spec_bg_code, d->spec_bg_stages, d->spec_bg_tile16) != CC_OK) d->spec_bg_error = cc_last_error();
+  if (st == 2 && spec_install(d, d->spec_bg_code, d->spec_bg_stages, d->spec_bg_tmode) != CC_OK) d->spec_bg_error = cc_last_error();
   d->spec_bg_code.clear();
   d->spec_bg_state.store(0, std::memory_order_release);
 }
@@ -2697,12 +2920,12 @@ static cc_status spec_start_background(cc_detector* d, int n_stages) {
   d->spec_thread = std::thread([d, n_stages, arch]() {
     std::vector<char> code;
     int k = 0;
-    bool t16 = false;
-    const cc_status s2 = spec_build(d->m, n_stages, arch, code, k, t16);
+    int tmode = 0;
+    const cc_status s2 = spec_build(d->m, n_stages, arch, code, k, tmode);
     if (s2 == CC_OK) {
       d->spec_bg_code.swap(code);
       d->spec_bg_stages = k;
-      d->spec_bg_tile16 = t16;
+      d->spec_bg_tmode = tmode;
       d->spec_bg_state.store(2, std::memory_order_release);
     } else {
       d->spec_bg_error = cc_last_error();  // this thread's message
@@ -2924,10 +3147,10 @@ cc_status cc_detector_specialize(cc_detector* d, int n_stages) {
   if (st != CC_OK) return st;
   std::vector<char> code;
   int k = 0;
-  bool t16 = false;
-  st = spec_build(d->m, n_stages, arch, code, k, t16);
+  int tmode = 0;
+  st = spec_build(d->m, n_stages, arch, code, k, tmode);
   if (st != CC_OK) return st;
-  return spec_install(d, code, k, t16);
+  return spec_install(d, code, k, tmode);
 }
 
 cc_status cc_detector_specialize_async(cc_detector* d, int n_stages) {
@@ -2944,8 +3167,8 @@ cc_status cc_cascade_compile_specialized(const cc_cascade* c, int n_stages, cons
   if (!c || !arch || !code_bytes) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_compile_specialized: null argument");
   std::vector<char> code;
   int k = 0;
-  bool t16 = false;
-  const cc_status st = spec_build(c->m, std::max(1, n_stages), arch, code, k, t16);
+  int tmode = 0;
+  const cc_status st = spec_build(c->m, std::max(1, n_stages), arch, code, k, tmode);
   if (st != CC_OK) return st;
   *code_bytes = code.size();
   return CC_OK;

@@ -219,6 +219,46 @@ def test_tile16_kernels_match(lbp_xml, haar_xml, tmp_path, monkeypatch):
     assert all(a.shape == b.shape and (a == b).all() for a, b in zip(spec, plain))
 
 
+def test_pair_tile_kernels_match(haar_xml, tmp_path, monkeypatch):
+    """CCAMD_SPEC_PAIR16=1: STEP-2 tiles hold PAIRS of 16-bit entries (entry i and its neighbour in the plane), so two
+    windows two pixels apart share every LDS read and the corner arithmetic runs packed; the dense and the thread phase
+    work on slots of one or two windows. Codes, exit stages, stage sums and rectangles must stay bit-identical: the
+    stock-profile cascade fully / partly specialised (the table-driven stages of the thread phase and the wave phase use
+    the strip records), every setting of the wave-phase and stump-split switches, a cascade built only from rectangles of
+    >= 258 pixels (every stump in the strip form), and another window size."""
+    monkeypatch.setenv("CCAMD_SPEC_PAIR16", "1")
+    img, img2 = frame_natural(640, 360, 11), frame_uniform(300, 200, 12)
+    o = orc.load_cascade_xml(haar_xml)
+    for k in (7, 2, 1):
+        p = cc.CascadeClassifier(haar_xml)
+        assert p.specialize(k) == k
+        assert _same_as_oracle(p, o, img, 1.1) + _same_as_oracle(p, o, img2, 1.25) > 0
+    for env in ({"CCAMD_WAVE_BELOW": "0"}, {"CCAMD_WAVE_BELOW": "64"}, {"CCAMD_SPLIT_STUMPS": "0"}, {"CCAMD_WAVE_BELOW": "4", "CCAMD_SPEC_BUDGET": "60"}):
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        p = cc.CascadeClassifier(haar_xml)
+        assert p.specialize(7) >= 1
+        assert _same_as_oracle(p, o, img, 1.1) > 0
+        for kk in env:
+            monkeypatch.delenv(kk)
+    cal = np.stack([img[y:y + 24, x:x + 24] for y in range(0, 300, 9) for x in range(0, 600, 11)])
+    big = cf.tilted_stump_cascade(cal, seed=17, stage_sizes=(5, 8, 11, 14), tilted=False, min_area=258)
+    path = str(tmp_path / "big.xml")
+    open(path, "w").write(big)
+    ob = orc.load_cascade_xml(path)
+    for k in (4, 2):
+        p = cc.CascadeClassifier(path)
+        assert p.specialize(k) == k
+        assert _same_as_oracle(p, ob, img, 1.1) + _same_as_oracle(p, ob, img2, 1.25) > 0
+    frames = np.stack([frame_natural(480, 270, 20 + i) for i in range(6)])
+    p = cc.CascadeClassifier(haar_xml)
+    p.specialize(7)
+    spec = p.detect_batch(frames, 1.1, 3)
+    p.specialize(0)
+    plain = p.detect_batch(frames, 1.1, 3)
+    assert all(a.shape == b.shape and (a == b).all() for a, b in zip(spec, plain))
+
+
 def test_specialised_lbp_cascade(lbp_xml):
     """The stock LBP cascade (20 stages, 139 stumps) compiled whole: bit-exact like the table-driven kernel."""
     o = orc.load_cascade_xml(lbp_xml)

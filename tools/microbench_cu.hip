@@ -64,6 +64,35 @@ __global__ __launch_bounds__(1024) void k_valu(unsigned long long* out, int* sin
             : "+v"(a0), "+v"(a1)
             : "v"(f0), "v"(f1), "v"(a2), "v"(a3), "v"(a4), "v"(a5)
             : "vcc");
+      } else if (OP == 5) {  // packed 16-bit integer add (the pair tile's corner arithmetic)
+        asm volatile(
+            "v_pk_add_u16 %0, %0, %8\n v_pk_add_u16 %1, %1, %8\n v_pk_add_u16 %2, %2, %8\n v_pk_add_u16 %3, %3, %8\n"
+            "v_pk_add_u16 %4, %4, %8\n v_pk_add_u16 %5, %5, %8\n v_pk_add_u16 %6, %6, %8\n v_pk_add_u16 %7, %7, %8\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+            : "v"(i));
+      } else if (OP == 6) {  // conversion of one sign-extended half (SDWA operand)
+        asm volatile(
+            "v_cvt_f32_i32_sdwa %0, sext(%8) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_i32_sdwa %1, sext(%9) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+            "v_cvt_f32_i32_sdwa %2, sext(%10) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_i32_sdwa %3, sext(%11) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+            "v_cvt_f32_i32_sdwa %4, sext(%12) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_i32_sdwa %5, sext(%13) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+            "v_cvt_f32_i32_sdwa %6, sext(%14) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_i32_sdwa %7, sext(%15) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+            : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3), "=v"(f4), "=v"(f5), "=v"(f6), "=v"(f7)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+      } else if (OP == 7) {  // three-operand add
+        asm volatile(
+            "v_add3_u32 %0, %0, %8, %8\n v_add3_u32 %1, %1, %8, %8\n v_add3_u32 %2, %2, %8, %8\n v_add3_u32 %3, %3, %8, %8\n"
+            "v_add3_u32 %4, %4, %8, %8\n v_add3_u32 %5, %5, %8, %8\n v_add3_u32 %6, %6, %8, %8\n v_add3_u32 %7, %7, %8, %8\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+            : "v"(i));
+      } else if (OP == 8) {  // v_cmpx + add under the narrowed EXEC + restore: the specialised vote
+        asm volatile(
+            "s_mov_b64 s[20:21], exec\n v_cmpx_gt_f32_e32 0x3f000000, %2\n v_add_u32_e32 %0, 0x1234567, %0\n s_mov_b64 exec, s[20:21]\n"
+            "v_cmpx_gt_f32_e32 0x3f000000, %3\n v_add_u32_e32 %1, 0x1234567, %1\n s_mov_b64 exec, s[20:21]\n"
+            "v_cmpx_gt_f32_e32 0x3f000000, %2\n v_add_u32_e32 %0, 0x1234567, %0\n s_mov_b64 exec, s[20:21]\n"
+            "v_cmpx_gt_f32_e32 0x3f000000, %3\n v_add_u32_e32 %1, 0x1234567, %1\n s_mov_b64 exec, s[20:21]\n"
+            : "+v"(a0), "+v"(a1)
+            : "v"(f0), "v"(f1)
+            : "vcc", "s20", "s21");
       }
     }
   }
@@ -147,8 +176,9 @@ int main() {
   CK(hipMalloc(&d_out, sizeof(unsigned long long) * blocks));
   CK(hipMalloc(&d_sink, 4));
   CK(hipMalloc(&d_addr, 4 * 512));
-  const char* opname[] = {"v_add_u32", "v_add_f64", "v_cvt_f32_i32", "v_mul_f32", "cmp+2cndmask(x8 of 9 instr)"};
-  for (int op = 0; op < 5; op++)
+  const char* opname[] = {"v_add_u32", "v_add_f64", "v_cvt_f32_i32", "v_mul_f32", "cmp+2cndmask(x8 of 9 instr)", "v_pk_add_u16", "v_cvt_f32_i32_sdwa sext", "v_add3_u32",
+                          "v_cmpx+v_add (8 VALU of 8)"};
+  for (int op = 0; op < 9; op++)
     for (int half = 0; half < 2; half++)
       for (int wps : {1, 2, 4}) {
         const int threads = 256 * wps;
@@ -168,6 +198,14 @@ int main() {
           case 7: launch(k_valu<3, true>); break;
           case 8: launch(k_valu<4, false>); break;
           case 9: launch(k_valu<4, true>); break;
+          case 10: launch(k_valu<5, false>); break;
+          case 11: launch(k_valu<5, true>); break;
+          case 12: launch(k_valu<6, false>); break;
+          case 13: launch(k_valu<6, true>); break;
+          case 14: launch(k_valu<7, false>); break;
+          case 15: launch(k_valu<7, true>); break;
+          case 16: launch(k_valu<8, false>); break;
+          case 17: launch(k_valu<8, true>); break;
         }
         const double cyc = median_cycles(d_out, blocks);
         const double instr_per_simd = (double)ITER * 8 * wps;  // one block per CU: wps wavefronts on each SIMD
@@ -202,11 +240,16 @@ int main() {
   mk("b64 scattered, distinct, misaligned", [](int k, int l) { return 2 * ((l * 7 + k * 3) % 32) + 64 * ((l * 13 + k) % 75) + 1; });
   mk("b64 scattered, 4-byte class per half", [](int k, int l) { return ((l * 7 + k * 3) % 32) + 32 * ((l * 13 + k) % 150); });
   mk("b64 consecutive words (overlap)", [](int k, int l) { return k * 200 + l; });
-  for (int mode = 0; mode < 6; mode++)
+  const size_t n_b64 = pats.size();
+  // ds_read_b32 patterns of the pair tile's dense phase (mode 6): 16 pairs of one window row (even words) + the 16 below (odd row distance)
+  mk("b32 pair-dense: 16 x stride 2 + 16 x stride 2 at +309", [](int k, int l) { return k * 7 + ((l >> 4) & 1) * 309 + ((l >> 5) * 16 + (l & 15)) * 2; });
+  mk("b32 pair-dense, halves swapped (lanes 0-15,32-47 one row)", [](int k, int l) { return k * 7 + ((l >> 5) & 1) * 309 + (((l >> 4) & 1) * 16 + (l & 15)) * 2; });
+  mk("b32 stride 2 in 16 lanes, +1 per 16 lanes", [](int k, int l) { return k * 7 + (l & 15) * 2 + ((l >> 4) & 1) + (l >> 5) * 64; });
+  for (int mode = 0; mode < 7; mode++)
     for (size_t pi = 0; pi < pats.size(); pi++)
       for (int wps : {1, 4}) {
         const Pat& p = pats[pi];
-        if ((mode == 5) != (pi >= n_common)) continue;
+        if (mode == 5 ? !(pi >= n_common && pi < n_b64) : mode == 6 ? pi < n_b64 : pi >= n_common) continue;
         std::vector<int> w = p.w;
         if (mode == 2)
           for (auto& x : w) x &= ~1;
@@ -218,13 +261,14 @@ int main() {
           if (mode == 2) hipLaunchKernelGGL(k_lds<2>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
           if (mode == 3) hipLaunchKernelGGL(k_lds<3>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
           if (mode == 4) hipLaunchKernelGGL(k_lds<4>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
+          if (mode == 6) hipLaunchKernelGGL(k_lds<0>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
           if (mode == 5) hipLaunchKernelGGL(k_lds<2>, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_addr, d_out, d_sink);
         }
         CK(hipDeviceSynchronize());
         const double cyc = median_cycles(d_out, blocks);
         const double n_instr = (double)ITER * (mode == 1 ? 4 : 8) * wps * 4;  // wave-instructions per CU
-        const char* mname[] = {"ds_read_b32", "ds_read2_b32", "ds_read_b64", "ds_read_u16", "ds_read_u16_d16(+hi)", "ds_read_b64 (4B addr)"};
-        const double bytes_per_instr[] = {256.0, 512.0, 512.0, 128.0, 128.0, 512.0};
+        const char* mname[] = {"ds_read_b32", "ds_read2_b32", "ds_read_b64", "ds_read_u16", "ds_read_u16_d16(+hi)", "ds_read_b64 (4B addr)", "ds_read_b32"};
+        const double bytes_per_instr[] = {256.0, 512.0, 512.0, 128.0, 128.0, 512.0, 256.0};
         printf("LDS %-20s %-32s waves/CU=%2d : %.2f cycles per wave-instruction per CU (%.1f B/clk/CU)\n", mname[mode], p.name, wps * 4,
                cyc / n_instr, bytes_per_instr[mode] / (cyc / n_instr));
       }
