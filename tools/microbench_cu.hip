@@ -162,6 +162,49 @@ __global__ __launch_bounds__(1024) void k_lds(const int* __restrict__ addr, unsi
   if (s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7 == 123456789) sink[0] = 1;
 }
 
+
+// Do VALU work and LDS reads of the SAME wavefronts overlap? Per iteration 8 conflict-free ds_read_b32 (waited for at the end of the
+// iteration) and NV independent VALU instructions of one kind: 0 = none, 1 = v_add_u32 (VOP2), 2 = v_pk_add_u16 (VOP3P), 3 = v_add3_u32 (VOP3).
+// LDS = false drops the reads (VALU alone).
+template <int KIND, int NV, bool LDS>
+__global__ __launch_bounds__(1024) void k_mix(unsigned long long* out, int* sink) {
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = i;
+  const int lane = threadIdx.x & 63;
+  int a[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = (k * 200 + lane) * 4;
+  int v0 = lane, v1 = lane + 1, v2 = lane + 2, v3 = lane + 3;
+  int t0v = 0, t1v = 0, t2v = 0, t3v = 0, t4v = 0, t5v = 0, t6v = 0, t7v = 0, acc = 0;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < ITER; i++) {
+    if (LDS)
+      asm volatile(
+          "ds_read_b32 %0, %8\n ds_read_b32 %1, %9\n ds_read_b32 %2, %10\n ds_read_b32 %3, %11\n"
+          "ds_read_b32 %4, %12\n ds_read_b32 %5, %13\n ds_read_b32 %6, %14\n ds_read_b32 %7, %15\n"
+          : "=&v"(t0v), "=&v"(t1v), "=&v"(t2v), "=&v"(t3v), "=&v"(t4v), "=&v"(t5v), "=&v"(t6v), "=&v"(t7v)
+          : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+#pragma unroll
+    for (int j = 0; j < NV / 4; j++) {
+      if (KIND == 1)
+        asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(i));
+      if (KIND == 2)
+        asm volatile("v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %1, %1, %4\n v_pk_add_u16 %2, %2, %4\n v_pk_add_u16 %3, %3, %4\n" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(i));
+      if (KIND == 3)
+        asm volatile("v_add3_u32 %0, %0, %4, %4\n v_add3_u32 %1, %1, %4, %4\n v_add3_u32 %2, %2, %4, %4\n v_add3_u32 %3, %3, %4, %4\n" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(i));
+    }
+    if (LDS) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      acc += t0v + t1v + t2v + t3v + t4v + t5v + t6v + t7v;
+    }
+  }
+  __syncthreads();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  if (acc + v0 + v1 + v2 + v3 == 123456789) sink[0] = 1;
+}
+
 static double median_cycles(unsigned long long* d_out, int n) {
   std::vector<unsigned long long> h((size_t)n);
   CK(hipMemcpy(h.data(), d_out, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
@@ -272,5 +315,24 @@ int main() {
         printf("LDS %-20s %-32s waves/CU=%2d : %.2f cycles per wave-instruction per CU (%.1f B/clk/CU)\n", mname[mode], p.name, wps * 4,
                cyc / n_instr, bytes_per_instr[mode] / (cyc / n_instr));
       }
+  // VALU + LDS in the same wavefronts: 20 wavefronts per CU (the cascade kernel's residency), cycles per iteration per CU
+  {
+    const int threads = 1024;  // 16 wavefronts per CU (one block per CU)
+    auto run = [&](const char* name, auto kern) {
+      for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 8192 * 4 + 1024, 0, d_out, d_sink);
+      CK(hipDeviceSynchronize());
+      printf("MIX %-44s : %.1f cycles per iteration of the block's 16 wavefronts\n", name, median_cycles(d_out, blocks) / ITER);
+    };
+    run("8 ds_read_b32 alone", k_mix<0, 0, true>);
+    run("8 v_add_u32 alone", k_mix<1, 8, false>);
+    run("16 v_add_u32 alone", k_mix<1, 16, false>);
+    run("8 v_pk_add_u16 alone", k_mix<2, 8, false>);
+    run("8 v_add3_u32 alone", k_mix<3, 8, false>);
+    run("8 ds_read_b32 + 8 v_add_u32", k_mix<1, 8, true>);
+    run("8 ds_read_b32 + 16 v_add_u32", k_mix<1, 16, true>);
+    run("8 ds_read_b32 + 8 v_pk_add_u16", k_mix<2, 8, true>);
+    run("8 ds_read_b32 + 8 v_add3_u32", k_mix<3, 8, true>);
+    run("8 ds_read_b32 + 4 v_pk_add_u16", k_mix<2, 4, true>);
+  }
   return 0;
 }
