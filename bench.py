@@ -142,6 +142,51 @@ def measure_extra_workload(cc, torch, dev, dev_index, cascade, specialize, frame
             "lds_frac": round(lds_ach / (256 * 128 * 2.4), 4), "rectangles_identical_to_cpu_oracle_frame0": same}
 
 
+def measure_training_eval(cc, torch):
+    """BASELINE configs[4] beside the headline (rank 0, N = 1): the trainer's bulk feature evaluation -- the Haar BASIC catalog
+    of a 24x24 window (162 336 features) over 10 000 positives + 10 000 negatives, written as the out[feature][sample] matrix
+    CvCascadeBoostTrainData::precalculate fills (o_cvcascadeboosttraindata.cpp:582-596), in row blocks into one resident
+    buffer. Kernel time by HIP events; one row block is compared bit for bit with the CPU oracle."""
+    import numpy as np
+    from cascadeclassifier_amd import evaluator as ev
+    rng = np.random.default_rng(7)
+    n = 10000
+    tmpl = rng.integers(0, 256, (24, 24)).astype(np.float64)
+    pos = np.clip(np.rint(tmpl + rng.normal(0, 15, (n, 24, 24))), 0, 255).astype(np.uint8)
+    neg = rng.integers(0, 256, (n, 24, 24), dtype=np.uint8)
+    imgs, labels = np.concatenate([pos, neg]), np.concatenate([np.ones(n, np.uint8), np.zeros(n, np.uint8)])
+    N = len(imgs)
+    e = cc.CvFeatureEvaluator.create(ev.HAAR)
+    e.init(cc.CvFeatureParams(ev.HAAR, ev.BASIC), N, (24, 24))
+    nfeat = e.getNumFeatures()
+    e.setImages(imgs, labels)
+    block = 32768
+    out = torch.empty((block, N), dtype=torch.float32, device="cuda")
+    e.calc_batch_device(0, block, out.data_ptr(), n_samples=N)  # warm-up
+    torch.cuda.synchronize()
+    kernel_ms, launches = 0.0, 0
+    t0 = time.perf_counter()
+    for f0 in range(0, nfeat, block):
+        e.calc_batch_device(f0, min(f0 + block, nfeat), out.data_ptr(), n_samples=N)
+        kernel_ms += e.last_kernel_ms()
+        launches += 1
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    f0, f1 = 100000, 100000 + 512
+    e.calc_batch_device(f0, f1, out.data_ptr(), n_samples=N)
+    torch.cuda.synchronize()
+    got = out[: f1 - f0].cpu().numpy()
+    from oracle import oracle as orc
+    s, t, nf = orc.set_images(imgs, want_tilted=False)
+    want = orc.haar_eval_batch(orc.haar_catalog(24, 24, ev.BASIC), f0, f1, s, t, nf, 24, 24)
+    evals = nfeat * N
+    return {"workload": f"CvHaarEvaluator bulk evaluation for one boosting stage: Haar BASIC {nfeat} features x {N} samples of 24x24 -- BASELINE configs[4]",
+            "value": round(evals / (kernel_ms * 1e-3) / 1e9, 2), "unit": "G feature evaluations/s (kernel time)", "kernel_ms": round(kernel_ms, 3),
+            "launches": launches, "wall_ms": round(wall * 1e3, 3), "hbm_write_GBps": round(evals * 4 / (kernel_ms * 1e-3) / 1e9, 1),
+            "roofline_frac_hbm": round(evals * 4 / (kernel_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+            "values_identical_to_cpu_oracle_rows": [f0, f1], "values_identical_to_cpu_oracle": bool((got.view(np.uint32) == want.view(np.uint32)).all())}
+
+
 def spawn_ranks(n):
     """Starts n copies of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, 127.0.0.1 rendezvous on a free port) and
     waits for them. Returns the first non-zero exit status, or 0. If one rank dies the others are terminated, so a
@@ -487,8 +532,9 @@ def main():
             "value_1_thread_sample": "frame 0 once",
             "rectangles_identical_to_gpu": ok if last is not None else None,
         }
-    # The workloads SURVEY.md 8d lists beside the headline, each as a short run of the same step (rank 0, N = 1): the stock
-    # LBP cascade (BASELINE configs[2]) and the headline cascade on i.i.d. uniform noise (distribution (i)).
+    # The workloads SURVEY.md 8d lists beside the headline, each as a short run (rank 0, N = 1): the stock LBP cascade
+    # (BASELINE configs[2]), the headline cascade on i.i.d. uniform noise (distribution (i)), and the trainer's bulk feature
+    # evaluation (BASELINE configs[4]).
     if extra_legs:
         del clf
         extras = []
@@ -501,6 +547,7 @@ def main():
                 extras.append(measure_extra_workload(cc, torch, dev, dev_index, args.cascade, args.specialize,
                                                      make_frames(B, W, H, seed0=0, content="uniform"), args,
                                                      f"{W}x{H} headline cascade on i.i.d. uniform noise (SURVEY 8d distribution (i))"))
+            extras.append(measure_training_eval(cc, torch))
         except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
             extras.append({"error": str(e)})
         out["extra_workloads"] = extras
@@ -512,8 +559,9 @@ def main():
         dist.destroy_process_group()
     if out.get("cpu_baseline", {}).get("rectangles_identical_to_gpu") is False:
         sys.exit("bench.py: GPU rectangles differ from the CPU oracle on the baseline sample: the number above is invalid")
-    if any(e.get("rectangles_identical_to_cpu_oracle_frame0") is False for e in out.get("extra_workloads", [])):
-        sys.exit("bench.py: an extra workload's GPU rectangles differ from the CPU oracle")
+    if any(e.get("rectangles_identical_to_cpu_oracle_frame0") is False or e.get("values_identical_to_cpu_oracle") is False
+           for e in out.get("extra_workloads", [])):
+        sys.exit("bench.py: an extra workload's GPU results differ from the CPU oracle")
 
 
 if __name__ == "__main__":
