@@ -259,6 +259,24 @@ def test_pair_tile_kernels_match(haar_xml, tmp_path, monkeypatch):
     assert all(a.shape == b.shape and (a == b).all() for a, b in zip(spec, plain))
 
 
+def test_shared_corners_between_stumps_do_not_change_results(haar_xml, monkeypatch):
+    """The generator re-orders the stumps of a stage (where the stage sum is exact) so that neighbours share rectangle
+    corners, and a stump takes the shared words from its predecessor's registers instead of reading them again
+    (CCAMD_SPEC_NO_SHARE=1: original order, every corner read; CCAMD_SPEC_SHARE_WINDOW: how many predecessors). Every variant
+    must give the oracle's codes, exit stages, stage sums and rectangles -- also through the stump-split path, whose calls
+    start in the middle of a stage."""
+    img = frame_natural(640, 360, 11)
+    o = orc.load_cascade_xml(haar_xml)
+    for env in ({}, {"CCAMD_SPEC_NO_SHARE": "1"}, {"CCAMD_SPEC_SHARE_WINDOW": "3"}, {"CCAMD_WAVE_BELOW": "0"}, {"CCAMD_SPEC_TILE16": "1"}):
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        p = cc.CascadeClassifier(haar_xml)
+        assert p.specialize(7) == 7
+        assert _same_as_oracle(p, o, img, 1.1) > 0
+        for kk in env:
+            monkeypatch.delenv(kk)
+
+
 def test_specialised_lbp_cascade(lbp_xml):
     """The stock LBP cascade (20 stages, 139 stumps) compiled whole: bit-exact like the table-driven kernel."""
     o = orc.load_cascade_xml(lbp_xml)
