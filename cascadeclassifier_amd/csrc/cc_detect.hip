@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <sstream>
 #include <future>
 #include <memory>
 #include <thread>
@@ -2779,6 +2780,12 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
   if (lbp) optv.push_back("-DCC_SPEC_LBP");
   if (tile16) optv.push_back("-DCC_SPEC_TILE16");
   if (tmode == TILE_PAIR16) optv.push_back("-DCC_SPEC_PAIR16");
+  std::vector<std::string> extra;  // tuning: further compiler options, space-separated
+  if (const char* e = std::getenv("CCAMD_SPEC_EXTRA_FLAGS")) {
+    std::istringstream is(e);
+    for (std::string w; is >> w;) extra.push_back(w);
+  }
+  for (const std::string& w : extra) optv.push_back(w.c_str());
   const char* const* opts = optv.data();
   const int n_opts = (int)optv.size();
   std::string key;  // everything the code object depends on: compiler version, options, then the source
