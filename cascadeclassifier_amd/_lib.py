@@ -94,6 +94,7 @@ SIGNATURES = {
     "cc_detect_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _sz, C.POINTER(DetectParams), _vp, _i, _vp]),
     "cc_detect_batch_submit": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _sz, C.POINTER(DetectParams), _pp]),
     "cc_detect_batch_collect": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "cc_detect_batch_discard": (_i, [_vp, _vp]),
     "cc_detect_batch_device_only": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _sz, C.POINTER(DetectParams)]),
     "cc_detect_multiscale_levels": (_i, [_vp, _vp, _i, _i, _sz, C.POINTER(DetectParams), _vp, _vp, _vp, _i, C.POINTER(_i)]),
     "cc_detect_raw": (_i, [_vp, _vp, _i, _i, _sz, C.POINTER(DetectParams), _vp, _i, C.POINTER(_i)]),

@@ -3413,6 +3413,19 @@ cc_status cc_detect_batch_collect(cc_detector* d, cc_batch_ticket* t, cc_rect* o
   return CC_OK;
 }
 
+cc_status cc_detect_batch_discard(cc_detector* d, cc_batch_ticket* t) {
+  if (!t) return CC_OK;
+  std::unique_ptr<cc_batch_ticket> own(t);
+  if (!d || t->owner != d) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch_discard: the ticket belongs to another detector");
+  if (d->pending.active && d->pending.sink == t->sink) {  // let its last pass finish and drop what it delivers
+    cc_status st = ensure_device(d->device);
+    if (st != CC_OK) return st;
+    (void)retire_pending(d);
+  }
+  t->sink->wait_jobs();
+  return CC_OK;
+}
+
 cc_status cc_detect_multiscale(cc_detector* d, const uint8_t* gray, int width, int height, size_t row_stride,
                                const cc_detect_params* p, cc_rect* out, int cap, int* n) {
   if (!n) return set_error(CC_ERR_INVALID_ARG, "cc_detect_multiscale: null count pointer");

@@ -238,6 +238,12 @@ class CascadeClassifier:
             L.check(st)
             return [out[offs[i]:offs[i + 1]].copy() for i in range(n)]
 
+    def detect_batch_discard(self, ticket):
+        """Ends a submitted batch whose results are not wanted (cc_detect_batch_discard)."""
+        t, ticket["ticket"], ticket["frames"] = ticket["ticket"], None, None
+        if t is not None:
+            L.check(L.lib().cc_detect_batch_discard(self._detector(), t))
+
     def run_device_only(self, device_ptr, shape, scaleFactor=1.1, minSize=None, maxSize=None, row_stride=None,
                         frame_stride=None):
         n, h, w = shape

@@ -160,13 +160,15 @@ CC_API cc_status cc_detect_batch_device_only(cc_detector* d, const uint8_t* fram
  * is left unfetched inside the detector: a later submit (or any other detection call) fetches it first; results stay in
  * the ticket until collect. Frames (device or host memory) must stay valid until the batch is collected. collect frees
  * the ticket, except when it returns CC_ERR_BUFFER_TOO_SMALL (offsets[n_frames] then holds the count: collect again with
- * room for it); a ticket that is never collected leaks. No reference counterpart (the reference handles one
- * image per call, tools/detection/Cpp/main.cpp:42-45). */
+ * room for it). cc_detect_batch_discard ends a ticket whose results are not wanted (it waits for the batch's last pass;
+ * NULL is accepted); a ticket that is neither collected nor discarded leaks. No reference counterpart (the reference
+ * handles one image per call, tools/detection/Cpp/main.cpp:42-45). */
 typedef struct cc_batch_ticket cc_batch_ticket;
 CC_API cc_status cc_detect_batch_submit(cc_detector* d, const uint8_t* frames, int on_device, int n_frames, int width,
                                         int height, size_t row_stride, size_t frame_stride, const cc_detect_params* p,
                                         cc_batch_ticket** ticket);
 CC_API cc_status cc_detect_batch_collect(cc_detector* d, cc_batch_ticket* ticket, cc_rect* out, int cap, int32_t* offsets);
+CC_API cc_status cc_detect_batch_discard(cc_detector* d, cc_batch_ticket* ticket);
 
 /* The outputRejectLevels overload of cv::CascadeClassifier::detectMultiScale (objects, rejectLevels, levelWeights,
  * ..., outputRejectLevels = true; OpenCV 4.6.0 objdetect, no call site in the reference: SURVEY.md 8f-4). Windows that

@@ -273,6 +273,13 @@ def test_submit_collect_pipelines_batches_with_identical_results(haar_xml, lbp_x
     t7 = q.detect_batch_submit(b, 1.1, 2)
     same(q.detect_batch_collect(t6), "a")
     same(q.detect_batch_collect(t7), "b")
+    # a batch nobody wants: discarded while it is pending and after another submit fetched it; the detector carries on
+    t10 = q.detect_batch_submit(a, 1.1, 2)
+    q.detect_batch_discard(t10)
+    t11, t12 = q.detect_batch_submit(b, 1.1, 2), q.detect_batch_submit(a, 1.1, 2)
+    q.detect_batch_discard(t11)
+    q.detect_batch_discard(t11)                    # a second time: nothing left to do
+    same(q.detect_batch_collect(t12), "a")
     # LBP (wave phase, 16-bit tiles) through the same path
     r = cc.CascadeClassifier(lbp_xml, max_batch=8)
     r.specialize(20)
