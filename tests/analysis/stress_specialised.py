@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""One-off stress run for the kernel generator (not part of the suite): random upright stump cascades -- random stage
+counts and stage sizes from 1 stump up, random leaves -- specialised as far as the budget allows and compared with the CPU
+oracle window by window (result codes, exit stages, stage sums, visited flags, rectangles) on a natural-like and a
+uniform-noise frame. The shapes the generator treats differently all occur: stages shorter than the four parts of a stage,
+stages whose sums are exact (fixed-point votes, stumps re-ordered to share corners) and not (float accumulation in the
+cascade's order), rectangles whose sums exceed 16 bits. Usage on a GPU box: python tests/analysis/stress_specialised.py [n_cascades]
+Last run: profiles/r03_stress_specialised.txt."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import cascadeclassifier_amd as cc  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from tests import cascade_factory as cf  # noqa: E402
+from tests.util import frame_natural, frame_uniform  # noqa: E402
+
+
+def main():
+    n_cascades = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    img, img2 = frame_natural(416, 300, 7), frame_uniform(200, 150, 8)
+    cal = np.stack([img[y:y + 24, x:x + 24] for y in range(0, 270, 9) for x in range(0, 390, 11)])
+    t0 = time.time()
+    windows = 0
+    for seed in range(n_cascades):
+        rng = np.random.default_rng(1000 + seed)
+        sizes = tuple(int(v) for v in rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 47], size=int(rng.integers(2, 7))))
+        xml = cf.tilted_stump_cascade(cal, seed=seed, stage_sizes=sizes, tilted=False, min_area=int(rng.choice([16, 100, 258])))
+        path = f"/tmp/stress_{seed}.xml"
+        open(path, "w").write(xml)
+        o = orc.load_cascade_xml(path)
+        for env in ({}, {"CCAMD_SPEC_TILE16": "1"}, {"CCAMD_SPEC_PAIR16": "1"}):
+            os.environ.update(env)
+            p = cc.CascadeClassifier(path)
+            k = p.specialize(len(sizes))
+            for im, sf in ((img, 1.1), (img2, 1.3)):
+                ref = orc.detect_raw(o, im, sf, nthreads=8, full=True)
+                codes, sums, vis = p.debug_windows(im, sf)
+                assert (codes == ref.codes).all() and (sums == ref.sums).all() and (vis == ref.visited).all(), (seed, sizes, env)
+                a, b = p.detectMultiScale(im, sf, 2), orc.detect_multiscale(o, im, sf, 2, nthreads=8)
+                assert a.shape == b.shape and (a == b).all(), (seed, sizes, env)
+                windows += len(codes)
+            for kk in env:
+                del os.environ[kk]
+        print(f"cascade {seed}: stages {sizes}, {k} specialised: identical (32-bit, 16-bit and pair tiles)", flush=True)
+        os.remove(path)
+    print(f"{n_cascades} random cascades x 3 tile layouts x 2 frames: {windows} windows, every code / exit stage / stage sum / visited flag / "
+          f"rectangle identical to the CPU oracle ({time.time() - t0:.0f} s)")
+
+
+if __name__ == "__main__":
+    main()
