@@ -220,8 +220,10 @@ CC_API cc_status cc_detector_specialize_async(cc_detector* d, int n_stages);
 CC_API int cc_detector_specialized_stages(const cc_detector* d);
 CC_API cc_status cc_cascade_compile_specialized(const cc_cascade* c, int n_stages, const char* arch, size_t* code_bytes);
 
-/* Per-kernel device time accumulated since the last reset, measured with HIP events on the detector's stream.
- * Profiling is off by default (no events are recorded). */
+/* Per-kernel device time accumulated since the last reset, measured with HIP events on the detector's streams.
+ * Profiling is off by default (no events are recorded). A synchronous detection call reads its events before it
+ * returns; a submitted batch (cc_detect_batch_submit) does not wait for them: cc_detector_get_timings first waits for the
+ * detector's streams and reads what is outstanding. */
 typedef struct cc_detector_timings {
   double resize_ms, integral_ms, eval_ms, finalize_ms;
   int64_t resize_launches, integral_launches, eval_launches, finalize_launches;
