@@ -295,9 +295,12 @@ def main():
     gather_kind = "none (single rank)"
     if world > 1:
         gather_kind = f"torch.distributed all_gather ({args.backend})"
-        if args.backend == "nccl" and not os.environ.get("CCAMD_BENCH_TORCH_GATHER"):
+        # (CCAMD_COMM_TRANSPORT=tcp: the same C-ABI calls over the library's loopback transport -- the rehearsal of this leg
+        # on a one-GPU box, where RCCL refuses two ranks on one device)
+        tcp = os.environ.get("CCAMD_COMM_TRANSPORT") == "tcp"
+        if (args.backend == "nccl" or tcp) and not os.environ.get("CCAMD_BENCH_TORCH_GATHER"):
             from cascadeclassifier_amd.distributed import Comm
-            ok = torch.zeros(1, dtype=torch.int32, device=dev)
+            ok = torch.zeros(1, dtype=torch.int32, device=comm_dev)
             try:
                 comm = Comm.from_torch(dev_index)
                 ok += 1
@@ -305,8 +308,24 @@ def main():
                 print(f"[bench] rank {rank}: cc_comm_create failed ({e}); gathering with torch.distributed", file=sys.stderr)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks or none
             if int(ok.item()) == 1:
-                gather_kind = "cc_gather_detections (C ABI, RCCL ncclAllGather x2)"
+                # one trial gather before anything is timed: the C ABI's collective has run on CPU transports and on one rank
+                # only (no multi-GPU box so far); if it fails on any rank, every rank falls back to the torch collective
+                ok.fill_(0)
+                try:
+                    trial = gather_detections([np.array([[rank, 0, 1, 1]], np.int32)], device=comm_dev, comm=comm)
+                    if len(trial) == world and all(len(t) == 1 and int(t[0][0]) == r for r, t in enumerate(trial)):
+                        ok += 1
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench] rank {rank}: cc_gather_detections failed ({e}); gathering with torch.distributed", file=sys.stderr)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                gather_kind = "cc_gather_detections (C ABI, " + ("loopback TCP transport" if tcp else "RCCL ncclAllGather x2") + ")"
             else:
+                if comm is not None:
+                    try:
+                        comm.close()
+                    except Exception:  # noqa: BLE001
+                        pass
                 comm = None
 
     def step():

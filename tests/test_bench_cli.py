@@ -49,3 +49,17 @@ def test_bench_single_rank_line_has_roofline_and_cpu_baseline():
     assert out["n_gpus"] == 1
     assert out["roofline"]["bound"] in ("hbm", "mfma") and out["roofline"]["achieved"] > 0
     assert out["cpu_baseline"]["rectangles_identical_to_gpu"] is True
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_gather_through_the_c_abi_communicator(monkeypatch):
+    """The same two ranks with the gather of detections on the C ABI's communicator (cc_comm_* / cc_gather_detections) over
+    its loopback TCP transport -- the code the multi-GPU run executes with RCCL underneath, including the trial gather that
+    decides, on all ranks together, whether to fall back to the torch collective."""
+    monkeypatch.setenv("CCAMD_COMM_TRANSPORT", "tcp")
+    r = _run(["--gpus", "2", "--backend", "gloo", "--frames", "2", "--steps", "2", "--warmup", "1", "--width", "640", "--height", "480",
+              "--cpu-frames", "0"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert out["config"]["gather"].startswith("cc_gather_detections (C ABI, loopback TCP")
