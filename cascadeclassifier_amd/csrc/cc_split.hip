@@ -62,6 +62,59 @@ __global__ __launch_bounds__(256) void k_interleave(const float* __restrict__ va
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stable sort of every row of [rows][n] (one variable per row) with the sample position as the value: one block of 1024
+// threads per row, the whole row in registers + LDS (hipcub::BlockRadixSort: LSD radix, stable -- equal values keep
+// increasing sample order, what std::stable_sort over (value, index) gives the reference,
+// o_cvcascadeboosttraindata.cpp:582-596). A row of a boosting stage (<= 24 576 samples) fits a CU's LDS, so it is read
+// once and written once: 8 B + 8 B per element instead of the ~70 B of a device-wide segmented radix sort's four passes.
+// ------------------------------------------------------------------------------------------------
+constexpr int SORT_THREADS = 1024;
+template <int ITEMS>
+struct RowSort {
+  using Sort = hipcub::BlockRadixSort<float, SORT_THREADS, ITEMS, unsigned short>;
+  static constexpr size_t lds_bytes = sizeof(typename Sort::TempStorage);
+};
+template <int ITEMS>
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_rows_block(const float* __restrict__ vals, int rows, int n, float* __restrict__ keys_out,
+                                                                  int* __restrict__ idx_out) {
+  extern __shared__ __attribute__((aligned(16))) char sort_lds[];
+  using Sort = typename RowSort<ITEMS>::Sort;
+  typename Sort::TempStorage& temp = *reinterpret_cast<typename Sort::TempStorage*>(sort_lds);
+  const int row = blockIdx.x;
+  if (row >= rows) return;
+  const float* src = vals + (size_t)row * n;
+  float key[ITEMS];
+  unsigned short val[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {  // blocked arrangement: thread t owns positions t * ITEMS ..
+    const int pos = (int)threadIdx.x * ITEMS + i;
+    key[i] = pos < n ? src[pos] : __int_as_float(0x7f800000);  // padding sorts behind every finite value
+    val[i] = (unsigned short)pos;
+  }
+  Sort(temp).SortBlockedToStriped(key, val);
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {  // striped: rank = i * 1024 + t, consecutive lanes write consecutive ranks
+    const int rank = i * SORT_THREADS + (int)threadIdx.x;
+    if (rank < n) {
+      keys_out[(size_t)row * n + rank] = key[i];
+      idx_out[(size_t)row * n + rank] = (int)val[i];
+    }
+  }
+}
+template <int ITEMS>
+static hipError_t launch_sort_rows_block(const float* vals, int rows, int n, float* keys_out, int* idx_out, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr size_t lds = RowSort<ITEMS>::lds_bytes;
+  if (!attr_set && lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_block<ITEMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_sort_rows_block<ITEMS>), dim3((unsigned)rows), dim3(SORT_THREADS), lds, st, vals, rows, n, keys_out, idx_out);
+  return hipGetLastError();
+}
+
 __global__ void k_codes_u8(const float* __restrict__ in, uint8_t* __restrict__ out, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) out[i] = (uint8_t)(int)in[i];
@@ -346,13 +399,31 @@ cc_status cc_eval_presort_range(cc_evaluator* e, int fi_begin, int fi_end, int n
     const size_t total = (size_t)nf * N;
     st = launch_batch(e, true, feats, fi_begin + f0, fi_begin + f1, nullptr, N, e->d_out.p, 1, 0);
     if (st != CC_OK) return st;
-    size_t temp_bytes = 0;
-    CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
-                                                       offsets.p, offsets.p + 1, 0, 32, e->stream));
-    CC_HIP(temp.ensure(std::max<size_t>(temp_bytes, 1)));
-    // stable: equal values keep increasing sample order
-    CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(temp.p, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
-                                                       offsets.p, offsets.p + 1, 0, 32, e->stream));
+    static const bool device_sort_only = std::getenv("CCAMD_PRESORT_DEVICE_SORT") != nullptr;  // A/B: the device-wide sort for every size
+    if (!device_sort_only && N <= SORT_THREADS * 24) {  // a row fits one block: sorted in LDS, read once and written once
+      hipError_t he;
+      if (N <= SORT_THREADS * 4)
+        he = launch_sort_rows_block<4>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
+      else if (N <= SORT_THREADS * 8)
+        he = launch_sort_rows_block<8>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
+      else if (N <= SORT_THREADS * 12)
+        he = launch_sort_rows_block<12>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
+      else if (N <= SORT_THREADS * 16)
+        he = launch_sort_rows_block<16>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
+      else if (N <= SORT_THREADS * 20)
+        he = launch_sort_rows_block<20>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
+      else
+        he = launch_sort_rows_block<24>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
+      CC_HIP(he);
+    } else {
+      size_t temp_bytes = 0;
+      CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
+                                                         offsets.p, offsets.p + 1, 0, 32, e->stream));
+      CC_HIP(temp.ensure(std::max<size_t>(temp_bytes, 1)));
+      // stable: equal values keep increasing sample order
+      CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(temp.p, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
+                                                         offsets.p, offsets.p + 1, 0, 32, e->stream));
+    }
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((nf + 63) / 64));
     if (idx16)
       hipLaunchKernelGGL((k_interleave<uint16_t>), grid, dim3(256), 0, e->stream, keys_out.p, sorted.p, nf, N, e->d_sorted_val.p,
