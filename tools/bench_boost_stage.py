@@ -41,6 +41,13 @@ def main():
         imgs = np.concatenate([pos, neg])
     y = labels.astype(np.float64) * 2 - 1
     resp = y.astype(np.float32)
+    # process start-up (HIP context, code-object load) is not stage work: a throw-away evaluator takes it first
+    t0 = time.perf_counter()
+    w0 = cc.CvFeatureEvaluator.create(ev.HAAR)
+    w0.init(cc.CvFeatureParams(ev.HAAR, ev.BASIC), 64, (24, 24))
+    w0.setImages(imgs[:64], labels[:64])
+    del w0
+    t_startup = time.perf_counter() - t0
     t0 = time.perf_counter()
     e = cc.CvFeatureEvaluator.create(ev.HAAR)
     e.init(cc.CvFeatureParams(ev.HAAR, ev.BASIC), N, (24, 24))
@@ -82,7 +89,7 @@ def main():
         chosen.append(int(sp["var_idx"]))
         errs.append(float(np.mean(np.sign(F) != y)))
     out = {"data": "hard" if hard else "easy (SURVEY config 5)", "workload": f"Gentle AdaBoost, {rounds} stumps, Haar BASIC 24x24 ({e.getNumFeatures()} variables) x {N} samples (seed 7)",
-           "set_images_s": round(t_set, 3), "presort_s": round(t_presort, 3),
+           "process_startup_s": round(t_startup, 3), "set_images_s": round(t_set, 3), "presort_s": round(t_presort, 3),
            "per_weak_learner_ms": {"split_search_wall": round(t_split / rounds * 1e3, 3), "split_search_kernel": round(float(np.mean(kernel_ms)), 3),
                                    "feature_row": round(t_row / rounds * 1e3, 3), "host_bookkeeping_numpy": round(t_host / rounds * 1e3, 3)},
            "stage_total_s": round(t_set + t_presort + t_split + t_row + t_host, 3),
