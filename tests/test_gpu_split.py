@@ -124,6 +124,15 @@ def test_haar_root_node(boost_type, criteria):
     assert got["found"]
 
 
+@pytest.mark.parametrize("n", [5000, 9000, 13000, 17000, 24577])
+def test_presort_row_sizes(n):
+    """cc_eval_presort sorts a row of up to 24 576 samples with one block (registers + LDS; 4 ... 24 keys per thread are
+    separate kernel instances) and larger rows with the device-wide segmented sort: one size per instance and one past
+    the limit, with duplicated samples so that whole columns tie (equal values must keep increasing sample order)."""
+    e, _, labels, ints = _setup(ev.HAAR, ev.BASIC, (8, 8), n, seed=60 + n % 7, dup=n // 10)
+    _check(e, ev.HAAR, ev.BASIC, (8, 8), ints, labels, boost_type=ev.BOOST_GENTLE, seed=3)
+
+
 def test_haar_table_in_global_memory(monkeypatch):
     """Sample sets too large for the LDS-resident weight table take the global-memory gather path; force it here."""
     monkeypatch.setenv("CCAMD_SPLIT_GLOBAL_TABLE", "1")
