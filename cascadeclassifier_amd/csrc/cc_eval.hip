@@ -849,17 +849,21 @@ cc_status cc_eval_calc_batch_sorted(cc_evaluator* e, int fi_begin, int fi_end, i
   CC_HIP(offsets.ensure((size_t)nf + 1));
   st = launch_batch(e, haar, haar ? (const void*)e->d_haar.p : (const void*)e->d_lbp.p, fi_begin, fi_end, nullptr, n_samples, e->d_out.p, 1, 0);
   if (st != CC_OK) return st;
-  std::vector<int> off((size_t)nf + 1);
-  for (int i = 0; i <= nf; i++) off[(size_t)i] = i * n_samples;
-  CC_HIP(hipMemcpyAsync(offsets.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, e->stream));
-  hipLaunchKernelGGL(k_iota_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, iota.p, total, n_samples);
-  size_t temp_bytes = 0;
-  CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
-                                                     offsets.p, offsets.p + 1, 0, 32, e->stream));
-  CC_HIP(temp.ensure(std::max<size_t>(temp_bytes, 1)));
-  // radix sort is stable: equal values keep increasing sample order
-  CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(temp.p, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
-                                                     offsets.p, offsets.p + 1, 0, 32, e->stream));
+  if (n_samples <= sort_rows_block_limit()) {  // one block per row, the row in registers + LDS (cc_split.hip)
+    CC_HIP(sort_rows_block(e->d_out.p, nf, n_samples, keys_out.p, sorted.p, e->stream));
+  } else {
+    std::vector<int> off((size_t)nf + 1);
+    for (int i = 0; i <= nf; i++) off[(size_t)i] = i * n_samples;
+    CC_HIP(hipMemcpyAsync(offsets.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_iota_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, iota.p, total, n_samples);
+    size_t temp_bytes = 0;
+    CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
+                                                       offsets.p, offsets.p + 1, 0, 32, e->stream));
+    CC_HIP(temp.ensure(std::max<size_t>(temp_bytes, 1)));
+    // radix sort is stable: equal values keep increasing sample order
+    CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(temp.p, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
+                                                       offsets.p, offsets.p + 1, 0, 32, e->stream));
+  }
   if (idx_bytes == 2) {
     CC_HIP(narrow.ensure(total));
     hipLaunchKernelGGL(k_narrow_u16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, sorted.p, narrow.p, total);

@@ -65,6 +65,11 @@ struct PinnedBuf {
 
 cc_status eval_device(cc_evaluator* e);
 // Launches k_eval_batch over `feats` [fb, fe) for ns samples into d_out_ptr (device). Caller holds e->mu.
+// Stable sort of every row of [rows][n] with the sample position as the value, one block per row (cc_split.hip); only for
+// n <= sort_rows_block_limit(): larger rows take the device-wide segmented sort at the call site.
+int sort_rows_block_limit();
+hipError_t sort_rows_block(const float* vals, int rows, int n, float* keys_out, int* idx_out, hipStream_t st);
+
 cc_status launch_batch(cc_evaluator* e, bool haar, const void* feats, int fb, int fe, const int32_t* d_idx, int ns,
                        float* d_out_ptr, int normalized, size_t out_pitch /* 0 = n_samples */);
 

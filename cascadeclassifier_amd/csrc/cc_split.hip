@@ -115,6 +115,19 @@ static hipError_t launch_sort_rows_block(const float* vals, int rows, int n, flo
   return hipGetLastError();
 }
 
+int sort_rows_block_limit() {
+  static const bool device_sort_only = std::getenv("CCAMD_PRESORT_DEVICE_SORT") != nullptr;  // A/B: the device-wide sort for every size
+  return device_sort_only ? 0 : SORT_THREADS * 24;
+}
+hipError_t sort_rows_block(const float* vals, int rows, int n, float* keys_out, int* idx_out, hipStream_t st) {
+  if (n <= SORT_THREADS * 4) return launch_sort_rows_block<4>(vals, rows, n, keys_out, idx_out, st);
+  if (n <= SORT_THREADS * 8) return launch_sort_rows_block<8>(vals, rows, n, keys_out, idx_out, st);
+  if (n <= SORT_THREADS * 12) return launch_sort_rows_block<12>(vals, rows, n, keys_out, idx_out, st);
+  if (n <= SORT_THREADS * 16) return launch_sort_rows_block<16>(vals, rows, n, keys_out, idx_out, st);
+  if (n <= SORT_THREADS * 20) return launch_sort_rows_block<20>(vals, rows, n, keys_out, idx_out, st);
+  return launch_sort_rows_block<24>(vals, rows, n, keys_out, idx_out, st);
+}
+
 __global__ void k_codes_u8(const float* __restrict__ in, uint8_t* __restrict__ out, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) out[i] = (uint8_t)(int)in[i];
@@ -399,22 +412,8 @@ cc_status cc_eval_presort_range(cc_evaluator* e, int fi_begin, int fi_end, int n
     const size_t total = (size_t)nf * N;
     st = launch_batch(e, true, feats, fi_begin + f0, fi_begin + f1, nullptr, N, e->d_out.p, 1, 0);
     if (st != CC_OK) return st;
-    static const bool device_sort_only = std::getenv("CCAMD_PRESORT_DEVICE_SORT") != nullptr;  // A/B: the device-wide sort for every size
-    if (!device_sort_only && N <= SORT_THREADS * 24) {  // a row fits one block: sorted in LDS, read once and written once
-      hipError_t he;
-      if (N <= SORT_THREADS * 4)
-        he = launch_sort_rows_block<4>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
-      else if (N <= SORT_THREADS * 8)
-        he = launch_sort_rows_block<8>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
-      else if (N <= SORT_THREADS * 12)
-        he = launch_sort_rows_block<12>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
-      else if (N <= SORT_THREADS * 16)
-        he = launch_sort_rows_block<16>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
-      else if (N <= SORT_THREADS * 20)
-        he = launch_sort_rows_block<20>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
-      else
-        he = launch_sort_rows_block<24>(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream);
-      CC_HIP(he);
+    if (N <= sort_rows_block_limit()) {  // a row fits one block: sorted in LDS, read once and written once
+      CC_HIP(sort_rows_block(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream));
     } else {
       size_t temp_bytes = 0;
       CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
