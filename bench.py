@@ -413,14 +413,38 @@ def main():
                               "synchronous call spends on the host with the device idle; the headline's steps are submitted one ahead "
                               "(config.steps_are), which hides that and the first pass's unoverlapped pyramid / integral work. The device legs "
                               "of the passes overlap, so kernel_ms_per_step does not add up to either"}
+        # Host frames, in the headline's own step form: step i + 1 is submitted (its frames copied into the detector's pinned
+        # staging area and sent to the device on the front stream) before step i is collected.
+        def host_steps(n_steps):
+            out, prev = None, None
+            for _ in range(n_steps):
+                t = clf.detect_batch_submit(frames_host, args.scale_factor, args.min_neighbors)
+                if prev is not None:
+                    out = clf.detect_batch_collect(prev)
+                prev = t
+            return clf.detect_batch_collect(prev)
+        host_last = host_steps(2)
+        t1 = time.perf_counter()
+        host_last = host_steps(k)
+        hdt = (time.perf_counter() - t1) / k
         clf.detect_batch(frames_host, args.scale_factor, args.min_neighbors)
         t1 = time.perf_counter()
         for _ in range(k):
             clf.detect_batch(frames_host, args.scale_factor, args.min_neighbors)
-        hdt = (time.perf_counter() - t1) / k
+        hsync = (time.perf_counter() - t1) / k
+        host_same = last is not None and len(host_last) == len(last) and all(a.shape == b.shape and (a == b).all() for a, b in zip(host_last, last))
         host_frames_leg = {"ms_per_step": round(hdt * 1e3, 4), "value": round(windows_per_frame * B / hdt / 1e6, 3), "unit": "Mwindows/s",
-                           "what": f"the same step with the {B} frames in pageable host memory (H2D copies inside the call, {k} steps): the reference's "
-                                   "call shape; never the headline `value`"}
+                           "synchronous_call_ms_per_step": round(hsync * 1e3, 4),
+                           "synchronous_call_value": round(windows_per_frame * B / hsync / 1e6, 3),
+                           "rectangles_identical_to_resident_frames": bool(host_same),
+                           "what": f"the same steps with the {B} frames in pageable host memory (the reference's call shape, "
+                                   "tools/detection/Cpp/main.cpp:27-45), pipelined through cc_detect_batch_submit / _collect like the headline: "
+                                   "submit copies a pass's frames into the detector's pinned staging area (host threads) and issues ONE "
+                                   f"asynchronous H2D copy per pass on the front stream ({k} steps); synchronous_call_*: one cc_detect_batch per "
+                                   "step from the same host frames; never the headline `value`"}
+        if not host_same:
+            print("bench.py: rectangles from host frames differ from the resident-frame run", file=sys.stderr)
+            sys.exit(3)
 
     # windows the scan actually visits (grid windows minus the positions the stage-0 skip rule jumps over), frame 0,
     # outside the timed region (SURVEY.md §8d asks for it next to the grid count)
@@ -472,6 +496,10 @@ def main():
     out = {
         "metric": "detection Mwindows/sec (1080p, haarcascade_frontalface) + achieved HBM GB/s",
         "value": round(value, 3),
+        # the same metric for one synchronous cc_detect_batch call per step -- what rounds 1-2 reported as `value` (round 3 and
+        # later report pipelined steps, config.steps_are): use this one for trends across rounds and against the synchronous CPU
+        # baseline. Measured after the timed region (rank 0, N = 1); null where that leg does not run.
+        "value_synchronous": (round(value, 3) if args.sync_steps else (host_split["synchronous_call_value"] if host_split else None)),
         "unit": "Mwindows/s",
         "n_gpus": world,
         "steps": args.steps,

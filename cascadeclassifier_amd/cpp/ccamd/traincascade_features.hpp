@@ -103,10 +103,7 @@ class CvFeatureEvaluator {  // traincascade_features.h:155-188
   void presort(int nSamples) const;
   cc_split findBestSplit(const int* sampleIdx, int n, const double* subtreeWeights, const float* ordResponses,
                          const int* classLabels, double nodeValue, int boostType, int splitCriteria) const;
-  cc_evaluator* handle() const {  // for direct C-ABI calls: queued setImage() calls are sent first
-    flushImages();
-    return h;
-  }
+  cc_evaluator* handle() const { return h; }  // for direct C-ABI calls (the library itself sends queued setImage() images first)
 
  protected:
   virtual void generateFeatures() = 0;
@@ -125,12 +122,12 @@ class CvFeatureEvaluator {  // traincascade_features.h:155-188
   unsigned long long uid;  // unique per init(): the per-thread value caches belong to one initialised evaluator
   int lastSetIdx;          // sample index of the most recent setImage (a prediction walk asks for that sample)
 
-  // setImage() calls are queued on the host and reach the device as ONE cc_eval_set_images per run of consecutive
-  // indices, when something first reads (the positives / negatives of a stage are set one by one:
-  // cascadeclassifier.cpp:329-357). Guarded by a mutex: operator() is const and called from parallel_for_ workers.
-  void flushImages() const;
-  struct Pending;
-  mutable Pending* pending;
+  // setImage() is cc_eval_set_image: the library queues the window (it reaches the device in runs of consecutive
+  // indices when something first reads stored samples there -- the positives / negatives of a stage are set one by one,
+  // cascadeclassifier.cpp:329-357) and mirrors the window set LAST on the host, so that the prediction walk right behind
+  // a setImage (cascadeclassifier.cpp:346-347) is answered without a launch. `lastSetMirrored` says the sample set last
+  // went through that call (setImages() batches do not leave a mirror).
+  bool lastSetMirrored;
 };
 
 class CvHaarEvaluator : public CvFeatureEvaluator {  // haarfeatures.h:61-106

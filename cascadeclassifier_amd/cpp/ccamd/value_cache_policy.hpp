@@ -43,6 +43,14 @@ struct ValueCacheIndex {
     generation = gen;
   }
   int list_slot(int fi) const { return slot.empty() ? -1 : slot[(size_t)fi]; }
+  // access() answers MISS_* after it has already recorded the row / the list values as cached (the caller fills them next).
+  // If that evaluation fails the record must go, or the next access of the same feature / sample would be a HIT on values
+  // that were never produced. The learned list itself stays (it holds feature indices, not values).
+  void evaluation_failed() {
+    row_fi = -1;
+    list_si = -1;
+    have_miss = false;
+  }
 
   // Classifies the access (fi, si). On MISS_LIST the feature is in `list` afterwards (the caller evaluates the whole list
   // for sample si and then reads position list_slot(fi)); on MISS_ROW the caller evaluates row fi.

@@ -386,17 +386,10 @@ CvLBPFeatureParams::CvLBPFeatureParams() {  // lbpfeatures.cpp:9-13
 }
 
 // ---------------------------------------------------------------- evaluator base
-struct CvFeatureEvaluator::Pending {
-  std::mutex mu;
-  int first = -1, n = 0;
-  std::vector<uchar> pixels, labels;
-};
-
 CvFeatureEvaluator::CvFeatureEvaluator()
-    : npos(0), nneg(0), numFeatures(0), featureParams(nullptr), h(nullptr), maxSampleCount(0), generation(0), uid(0), lastSetIdx(-1), pending(nullptr) {}
+    : npos(0), nneg(0), numFeatures(0), featureParams(nullptr), h(nullptr), maxSampleCount(0), generation(0), uid(0), lastSetIdx(-1), lastSetMirrored(false) {}
 
 CvFeatureEvaluator::~CvFeatureEvaluator() {
-  delete pending;
   if (h) cc_eval_destroy(h);
 }
 
@@ -410,7 +403,8 @@ void CvFeatureEvaluator::init(const CvFeatureParams* _featureParams, int _maxSam
     cc_eval_destroy(h);
     h = nullptr;
   }
-  if (pending) pending->n = 0;  // images queued for the previous evaluator go with it
+  lastSetIdx = -1;
+  lastSetMirrored = false;
   check(cc_eval_create(featureType(), haarMode(), winSize.width, winSize.height, _maxSampleCount, /*device=*/0, &h),
         "CvFeatureEvaluator::init");
   // `cls` is a header over the library's host label array: CvCascadeBoostTrainData wraps it without copying
@@ -426,56 +420,30 @@ void CvFeatureEvaluator::setImage(const cv::Mat& img, uchar clsLabel, int idx) {
   CV_Assert(img.rows == winSize.height);
   CV_Assert(idx >= 0 && idx < cls.rows);
   CV_Assert(img.type() == CV_8UC1);
-  if (!pending) pending = new Pending;
-  {
-    std::lock_guard<std::mutex> lk(pending->mu);
-    if (pending->n > 0 && idx != pending->first + pending->n) {  // not the next index of the run: send the run first
-      check(cc_eval_set_images(h, pending->pixels.data(), pending->n, pending->first, pending->labels.data()), "CvFeatureEvaluator::setImage");
-      pending->n = 0;
-    }
-    if (pending->n == 0) {
-      pending->first = idx;
-      pending->pixels.clear();
-      pending->labels.clear();
-    }
-    for (int y = 0; y < img.rows; y++) pending->pixels.insert(pending->pixels.end(), img.ptr<uchar>(y), img.ptr<uchar>(y) + img.cols);
-    pending->labels.push_back(clsLabel);
-    pending->n++;
-  }
-  cls.at<float>(idx, 0) = (float)clsLabel;  // getCls() answers from host memory at once (features.cpp:88)
-  generation++;
+  check(cc_eval_set_image(h, img.ptr<uchar>(0), img.rows > 1 ? (size_t)(img.ptr<uchar>(1) - img.ptr<uchar>(0)) : (size_t)img.cols, clsLabel, idx),
+        "CvFeatureEvaluator::setImage");
+  generation++;  // cls(idx) was written by the library: getCls() answers from host memory at once (features.cpp:88)
   lastSetIdx = idx;
-}
-
-void CvFeatureEvaluator::flushImages() const {
-  if (!pending) return;
-  std::lock_guard<std::mutex> lk(pending->mu);
-  if (pending->n == 0) return;
-  const int n = pending->n;
-  pending->n = 0;
-  check(cc_eval_set_images(h, pending->pixels.data(), n, pending->first, pending->labels.data()), "CvFeatureEvaluator::setImage");
+  lastSetMirrored = true;
 }
 
 void CvFeatureEvaluator::setImages(const uchar* imgs, int n, int first_idx, const uchar* labels) {
-  flushImages();
   check(cc_eval_set_images(h, imgs, n, first_idx, labels), "CvFeatureEvaluator::setImages");
   generation++;
   lastSetIdx = first_idx + n - 1;
+  lastSetMirrored = false;
 }
 
 void CvFeatureEvaluator::calcBatch(int fiBegin, int fiEnd, const int* sampleIdx, int nSamples, float* out) const {
-  flushImages();
   check(cc_eval_calc_batch(h, fiBegin, fiEnd, sampleIdx, nSamples, out, 0), "CvFeatureEvaluator::calcBatch");
 }
 
 void CvFeatureEvaluator::presort(int nSamples) const {
-  flushImages();
   check(cc_eval_presort(h, nSamples), "CvFeatureEvaluator::presort");
 }
 
 cc_split CvFeatureEvaluator::findBestSplit(const int* sampleIdx, int n, const double* subtreeWeights, const float* ordResponses,
                                            const int* classLabels, double nodeValue, int boostType, int splitCriteria) const {
-  flushImages();
   cc_split sp;
   check(cc_eval_find_best_split(h, sampleIdx, n, subtreeWeights, ordResponses, classLabels, nodeValue, boostType, splitCriteria, &sp,
                                 nullptr, nullptr),
@@ -484,30 +452,40 @@ cc_split CvFeatureEvaluator::findBestSplit(const int* sampleIdx, int n, const do
 }
 
 void CvFeatureEvaluator::calcBatchSorted(int fiBegin, int fiEnd, int nSamples, float* vals, void* sortedIdx, bool idx16) const {
-  flushImages();
   check(cc_eval_calc_batch_sorted(h, fiBegin, fiEnd, nSamples, vals, sortedIdx, idx16 ? 2 : 4), "CvFeatureEvaluator::calcBatchSorted");
 }
 
 float CvFeatureEvaluator::cachedValue(int featureIdx, int sampleIdx) const {
   CV_Assert(sampleIdx >= 0 && sampleIdx < maxSampleCount);
   CV_Assert(featureIdx >= 0 && featureIdx < numFeatures);
+  if (lastSetMirrored && sampleIdx == lastSetIdx) {  // the window set last: the library answers from its host mirror
+    float v = 0.f;
+    check(cc_eval_calc(h, featureIdx, sampleIdx, &v), "CvFeatureEvaluator::operator()");
+    return v;
+  }
   ValueCache& c = g_cache;
-  switch (c.ix.access(featureIdx, sampleIdx, uid, generation, lastSetIdx, numFeatures)) {
-    case ccamd::ValueCacheIndex::HIT_ROW:
-      return c.row[(size_t)sampleIdx];
-    case ccamd::ValueCacheIndex::HIT_LIST:
-      return c.col[(size_t)c.ix.list_slot(featureIdx)];
-    case ccamd::ValueCacheIndex::MISS_LIST:
-      flushImages();
-      c.col.resize(c.ix.list.size());
-      check(cc_eval_calc_list(h, c.ix.list.data(), (int)c.ix.list.size(), sampleIdx, c.col.data()), "CvFeatureEvaluator::operator()");
-      return c.col[(size_t)c.ix.list_slot(featureIdx)];
-    case ccamd::ValueCacheIndex::MISS_ROW:
-    default:
-      flushImages();
-      c.row.resize((size_t)maxSampleCount);
-      check(cc_eval_calc_batch(h, featureIdx, featureIdx + 1, nullptr, maxSampleCount, c.row.data(), 0), "CvFeatureEvaluator::operator()");
-      return c.row[(size_t)sampleIdx];
+  const ccamd::ValueCacheIndex::Access a = c.ix.access(featureIdx, sampleIdx, uid, generation, lastSetIdx, numFeatures);
+  try {
+    switch (a) {
+      case ccamd::ValueCacheIndex::HIT_ROW:
+        return c.row[(size_t)sampleIdx];
+      case ccamd::ValueCacheIndex::HIT_LIST:
+        return c.col[(size_t)c.ix.list_slot(featureIdx)];
+      case ccamd::ValueCacheIndex::MISS_LIST:
+        c.col.resize(c.ix.list.size());
+        check(cc_eval_calc_list(h, c.ix.list.data(), (int)c.ix.list.size(), sampleIdx, c.col.data()), "CvFeatureEvaluator::operator()");
+        return c.col[(size_t)c.ix.list_slot(featureIdx)];
+      case ccamd::ValueCacheIndex::MISS_ROW:
+      default:
+        c.row.resize((size_t)maxSampleCount);
+        check(cc_eval_calc_batch(h, featureIdx, featureIdx + 1, nullptr, maxSampleCount, c.row.data(), 0), "CvFeatureEvaluator::operator()");
+        return c.row[(size_t)sampleIdx];
+    }
+  } catch (...) {
+    // access() recorded the row / list as cached before its values existed (round-3 advisor finding): a failed evaluation
+    // must not leave that claim behind, or the next access would hit stale or missing values
+    c.ix.evaluation_failed();
+    throw;
   }
 }
 

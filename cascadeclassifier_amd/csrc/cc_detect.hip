@@ -34,6 +34,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <unordered_set>
 
 #include "cc_internal.h"
 
@@ -857,6 +858,7 @@ using namespace ccamd;
 
 struct cc_detector {
   Cascade m;
+  unsigned long long serial = 0;  // unique per created detector (tickets name their owner by it, not by address alone)
   int device = 0;
   int max_batch = 1;
   int pass_capacity = 1;  // frames the per-pass workspace is sized for: the largest pass seen so far (<= max_batch)
@@ -865,6 +867,7 @@ struct cc_detector {
   DevBuf<int> d_stage_ntrees, d_stage_first;
   DevBuf<int> d_group_first;  // stage groups of the cascade kernel (EvalArgs::group_first), n_groups + 1 entries
   int n_groups = 0;
+  int dense_from = 0x7fffffff;  // first stage group whose queue is a plain list instead of a bank-class table (EvalArgs::dense_from)
   DevBuf<float> d_stage_thr;
   int wave_below = 0;
   int last_call_graph = 0;  // the last single-image call was one hipGraph launch (cc_detector_graph_active)
@@ -918,6 +921,8 @@ struct cc_detector {
   int* h_counts = nullptr;  // pinned, 2 x 2 ints
   uint8_t* h_frame = nullptr;  // pinned staging copy of a single host image (graph path)
   size_t h_frame_bytes = 0;
+  uint8_t* h_stage = nullptr;  // pinned staging area for batches of host frames, two slots like d_frames (stage_host_frames)
+  size_t h_stage_bytes = 0;
   int use_graph = 1;
   int early_skip = 1, full_sqsum = 0, pipeline_passes = 4, pipeline_passes_set = 0, even_passes = 0;  // tuning knobs, read once at creation
   hipStream_t copy_stream = nullptr;
@@ -963,6 +968,7 @@ struct cc_detector {
       if (e) (void)hipEventDestroy(e);
     if (h_counts) (void)hipHostFree(h_counts);
     if (h_frame) (void)hipHostFree(h_frame);
+    if (h_stage) (void)hipHostFree(h_stage);
   }
 };
 
@@ -1867,6 +1873,41 @@ static std::string spec_stage_source_lbp(const Cascade& m, int n_stages, bool ti
                (unsigned)w[1], (unsigned)w[0], (unsigned)w[3], (unsigned)w[2], (unsigned)w[5], (unsigned)w[4], (unsigned)w[7], (unsigned)w[6],
                win.c_str(), hexf(d.left).c_str(), hexf(d.right).c_str());
       out.compute = t + buf;
+      if (const char* dbg = std::getenv("CCAMD_DEBUG_SPEC_MODE")) {
+        // Sensitivity experiments (as for Haar above): 3 = every corner read issued twice, 4 = the stump's arithmetic done
+        // twice on operands XOR-ed with a value the compiler cannot fold; results thrown away, decisions unchanged.
+        const int mode = std::atoi(dbg);
+        if (mode == 3) {
+          std::string dup;
+          for (int k = 0; k < 16; k++) {
+            snprintf(buf, sizeof(buf), "{ unsigned dz%d = (unsigned)%s%s[%d]; asm volatile(\"\" :: \"v\"(dz%d)); } ", k, h16 ? "h" : "b", win.c_str(), d.ofs[k] ^ 1, k);
+            dup += buf;
+          }
+          out.compute = dup + out.compute;
+        } else if (mode == 4) {
+          std::string dup = "{ const int zz = (int)__float_as_uint(vnf" + win + ") ^ 0x3f800001; double accd = 0.; int ";
+          for (int k = 0; k < 16; k++) dup += std::string(k ? ", " : "") + "d" + P[k] + " = " + P[k] + " ^ zz";
+          dup += "; ";
+          std::string body = out.compute;
+          for (int k = 15; k >= 0; k--) {  // p<local>_<k><win> -> dp...; longest names first so that p0_1 does not hit p0_10
+            size_t pos = 0;
+            while ((pos = body.find(P[k], pos)) != std::string::npos) {
+              const char next = pos + P[k].size() < body.size() ? body[pos + P[k].size()] : ' ';
+              const bool whole = !(next >= '0' && next <= '9') && (pos == 0 || body[pos - 1] != 'd');
+              if (whole) {
+                body.insert(pos, "d");
+                pos += P[k].size() + 1;
+              } else
+                pos += P[k].size();
+            }
+          }
+          const std::string accname = "acc" + win + " +=";
+          const size_t ap = body.find(accname);
+          if (ap != std::string::npos) body.replace(ap, accname.size(), "accd +=");
+          dup += body + " asm volatile(\"\" :: \"v\"(accd)); } ";
+          out.compute = dup + out.compute;
+        }
+      }
       return out;
     } else
     snprintf(buf, sizeof(buf), "acc%s += (double)((kSpecSubsets[%d][lbp >> 5] & (1 << (lbp & 31))) ? %s : %s); }", win.c_str(), index,
@@ -2299,6 +2340,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.stage_ntrees = d->d_stage_ntrees.p;
     A.group_first = d->d_group_first.p;
     A.ngroups = d->n_groups;
+    A.dense_from = d->dense_from;
     A.wave_below = d->wave_below;
     A.stop_after = d->stop_after;
     A.split_stumps = d->split_stumps;
@@ -2444,6 +2486,81 @@ static void retire_foreign(cc_detector* d) {
     sink->status = st;
     sink->error = cc_last_error();
   }
+}
+
+// Host frames -> the device staging area of `slot`, on the front stream. Pageable memory (what a caller of the reference's
+// shape hands over, tools/detection/Cpp/main.cpp:27-45) cannot be copied asynchronously: the runtime stages it through
+// its own pinned chunks on the calling thread, copy after copy, and the call returns when the last one is on the device
+// (round 3: a step of 64 Full-HD frames took 19.9 ms this way against 17.2 with resident frames). So the detector keeps
+// its own pinned staging area, double-buffered like the device one: the frames of a pass are copied into it by a few host
+// threads (tight rows), then ONE asynchronous copy on the front stream moves the pass to the device while the cascade
+// kernels of the pass before run -- and the caller's frames are free again when the call returns. The pinned slot is
+// reused two passes later; by then its pass has been retired (run_batch retires pass i when pass i + 1 is launched), so
+// its copy is long complete. Frames that already live in pinned memory (hipHostMalloc / hipHostRegister) skip the
+// staging copy.
+static cc_status stage_host_frames(cc_detector* d, const uint8_t* src, int nf, int width, int height, size_t row_stride,
+                                   size_t frame_stride, uint8_t* dev, size_t rs, size_t fs, int slot, hipStream_t front) {
+  hipPointerAttribute_t attr;
+  bool pinned = false;
+  if (hipPointerGetAttributes(&attr, src) == hipSuccess)
+    pinned = attr.type == hipMemoryTypeHost;
+  else
+    (void)hipGetLastError();  // ordinary pageable memory is "invalid value" to this query on some runtimes
+  static const bool no_stage = std::getenv("CCAMD_NO_PINNED_STAGING") != nullptr;  // the round-3 path, for A/B runs
+  if (pinned || no_stage) {
+    for (int f = 0; f < nf; f++)
+      CC_HIP(hipMemcpy2DAsync(dev + (size_t)f * fs, rs, src + (size_t)f * frame_stride, row_stride, (size_t)width, (size_t)height,
+                              hipMemcpyHostToDevice, front));
+    return CC_OK;
+  }
+  const size_t need = fs * (size_t)d->pass_capacity * 2;
+  if (d->h_stage_bytes < need) {
+    if (d->h_stage) {
+      CC_HIP(hipStreamSynchronize(front));  // no copy may still be reading the old area
+      (void)hipHostFree(d->h_stage);
+    }
+    d->h_stage = nullptr;
+    d->h_stage_bytes = 0;
+    CC_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->h_stage), need, hipHostMallocDefault));
+    d->h_stage_bytes = need;
+  }
+  uint8_t* hs = d->h_stage + (size_t)slot * fs * (size_t)d->pass_capacity;
+  auto copy_frames = [&](int fa, int fb) {
+    for (int f = fa; f < fb; f++) {
+      const uint8_t* sf = src + (size_t)f * frame_stride;
+      uint8_t* df = hs + (size_t)f * fs;
+      if (row_stride == rs)
+        std::memcpy(df, sf, (size_t)(height - 1) * rs + (size_t)width);
+      else
+        for (int y = 0; y < height; y++) std::memcpy(df + (size_t)y * rs, sf + (size_t)y * row_stride, (size_t)width);
+    }
+  };
+  static const int want_threads = []() {
+    if (const char* e = std::getenv("CCAMD_STAGE_THREADS")) return std::max(1, std::atoi(e));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(4u, hc / 2));
+  }();
+  const size_t total = fs * (size_t)nf;
+  const int nt = (int)std::min<size_t>((size_t)std::min(want_threads, nf), std::max<size_t>(1, total >> 21));  // >= 2 MB per thread
+  if (nt <= 1) {
+    copy_frames(0, nf);
+  } else {
+    std::vector<std::future<void>> jobs;
+    try {
+      for (int t = 1; t < nt; t++) {
+        const int fa = (int)((long long)nf * t / nt), fb = (int)((long long)nf * (t + 1) / nt);
+        jobs.push_back(std::async(std::launch::async, copy_frames, fa, fb));
+      }
+      copy_frames(0, nf / nt);
+      for (auto& j : jobs) j.get();
+    } catch (const std::exception& e) {
+      for (auto& j : jobs)
+        if (j.valid()) j.wait();
+      return set_error(CC_ERR_HIP, "staging host frames: %s", e.what());
+    }
+  }
+  CC_HIP(hipMemcpyAsync(dev, hs, total, hipMemcpyHostToDevice, front));
+  return CC_OK;
 }
 
 static void spec_poll(cc_detector* d);  // installs a finished background specialisation
@@ -2651,11 +2768,21 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     } else {  // staging area is double-buffered like the results
       ps.rs = (size_t)align_up(width, 4);
       ps.fs = ps.rs * (size_t)height;
-      CC_HIP(d->d_frames.ensure(ps.fs * (size_t)d->pass_capacity * 2));
+      const size_t need = ps.fs * (size_t)d->pass_capacity * 2;
+      if (d->d_frames.n < need && d->pending.active) {
+        // Growing the staging area frees it, and the unfetched pass still names its frames there (it would re-read them if
+        // it had to be redone: candidate-list overflow). Fetch it first (round-3 advisor finding).
+        if (d->pending.sink == sink) {
+          stt = retire_pending(d);
+          if (stt != CC_OK) return stt;
+        } else
+          retire_foreign(d);
+      }
+      CC_HIP(d->d_frames.ensure(need));
       uint8_t* stage = d->d_frames.p + (size_t)slot * ps.fs * (size_t)d->pass_capacity;
-      for (int f = 0; f < ps.nf; f++)
-        CC_HIP(hipMemcpy2DAsync(stage + (size_t)f * ps.fs, ps.rs, frames + (size_t)(f0 + f) * frame_stride, row_stride,
-                                (size_t)width, (size_t)height, hipMemcpyHostToDevice, front));
+      stt = stage_host_frames(d, frames + (size_t)f0 * frame_stride, ps.nf, width, height, row_stride, frame_stride, stage, ps.rs,
+                              ps.fs, slot, front);
+      if (stt != CC_OK) return stt;
       ps.dptr = stage;
     }
     // the slot's result buffers are free: the pass that used them last was retired when the pass after it was launched
@@ -3064,6 +3191,24 @@ int cc_device_count(void) {
   return n;
 }
 
+// Serial numbers of the detectors alive in this process. op 0: new serial (registered); 1: unregister `serial`;
+// 2: is `serial` alive (returns 1 / 0).
+static unsigned long long detector_registry(int op, unsigned long long serial) {
+  static std::mutex mu;
+  static std::unordered_set<unsigned long long> live;
+  static unsigned long long next = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (op == 0) {
+    live.insert(++next);
+    return next;
+  }
+  if (op == 1) {
+    live.erase(serial);
+    return 0;
+  }
+  return live.count(serial) ? 1 : 0;
+}
+
 cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_detector** out) {
   if (!c || !out) return set_error(CC_ERR_INVALID_ARG, "cc_detector_create: null argument");
   *out = nullptr;
@@ -3073,6 +3218,7 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   if (st != CC_OK) return st;
   std::unique_ptr<cc_detector> d(new cc_detector());
   d->m = c->m;
+  d->serial = detector_registry(0, 0);
   d->device = device;
   d->max_batch = max_batch;
   CC_HIP(hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking));
@@ -3159,6 +3305,17 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
     gf.push_back(nst);
     if (gf.size() < 2) gf.push_back(nst);  // no stage at all: one empty group, the kernels read group_first[1]
     d->n_groups = (int)gf.size() - 1;
+    // Queue form (EvalArgs::dense_from): LBP stump cascades switch from the bank-class table to a plain list at stage 2.
+    // There the tile is down to ~100 of its 512 windows: the table needs 6.2 rows for them (its fullest class) where a list
+    // needs 3.1, i.e. four wavefront passes over the group's 19 stumps instead of two, and the LBP kernel is bound by the
+    // vector ALU (73 % busy; LDS 52 %, profiles/r04_pmc_eval_lbp.json), not by the ~2.5-way bank conflicts the list costs.
+    // Haar cascades keep the table everywhere (LDS-bound; CCAMD_DENSE_FROM=<stage> to experiment).
+    int dense_stage = lbp ? 2 : -1;
+    if (const char* e = std::getenv("CCAMD_DENSE_FROM")) dense_stage = std::atoi(e);
+    d->dense_from = 0x7fffffff;
+    if (dense_stage >= 1)
+      for (int g = (int)gf.size() - 2; g >= 1; g--)
+        if (gf[(size_t)g] >= dense_stage) d->dense_from = g;
     CC_HIP(d->d_group_first.upload(gf, d->stream));
     CC_HIP(hipStreamSynchronize(d->stream));
   }
@@ -3231,6 +3388,7 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
 
 void cc_detector_destroy(cc_detector* d) {
   if (!d) return;
+  detector_registry(1, d->serial);
   (void)hipSetDevice(d->device);
   if (d->pending.active) {  // a submitted batch nobody collected: let the device finish, drop the results
     (void)hipStreamSynchronize(d->stream);
@@ -3365,13 +3523,37 @@ cc_status cc_detect_batch(cc_detector* d, const uint8_t* frames, int on_device, 
 
 struct cc_batch_ticket {
   cc_detector* owner = nullptr;
+  unsigned long long owner_serial = 0;  // cc_detector::serial of the owner: an address can be reused by a later detector
   int n_frames = 0;
   std::shared_ptr<BatchSink> sink;
-  std::vector<std::vector<cc_rect>> grouped;
-  ~cc_batch_ticket() {  // helper threads write into `grouped`: the ticket outlives them on every path
-    if (sink) sink->wait_jobs();
+  // Shared with the sink's consume function, NOT owned by the ticket alone: the detector may still hold the sink of a pass
+  // it has not fetched when the ticket ends on an error path, and that pass's helper then writes here (round-3 advisor
+  // finding: the function used to capture the ticket's address).
+  std::shared_ptr<std::vector<std::vector<cc_rect>>> grouped;
+  ~cc_batch_ticket() {
+    if (sink) {
+      try {
+        sink->wait_jobs();
+      } catch (...) {
+      }
+    }
   }
 };
+
+// The helper threads of a submitted batch run std::sort / std::vector code: what they throw (bad_alloc) surfaces in
+// future::get and must not cross the C ABI.
+static cc_status wait_sink_jobs(BatchSink& sink, const char* who) {
+  try {
+    sink.wait_jobs();
+  } catch (const std::exception& e) {
+    sink.jobs.clear();
+    return set_error(CC_ERR_HIP, "%s: grouping a pass failed on the host: %s", who, e.what());
+  } catch (...) {
+    sink.jobs.clear();
+    return set_error(CC_ERR_HIP, "%s: grouping a pass failed on the host", who);
+  }
+  return CC_OK;
+}
 
 cc_status cc_detect_batch_submit(cc_detector* d, const uint8_t* frames, int on_device, int n_frames, int width, int height,
                                  size_t row_stride, size_t frame_stride, const cc_detect_params* p, cc_batch_ticket** ticket) {
@@ -3381,17 +3563,18 @@ cc_status cc_detect_batch_submit(cc_detector* d, const uint8_t* frames, int on_d
   if (st != CC_OK) return st;
   std::unique_ptr<cc_batch_ticket> t(new cc_batch_ticket);
   t->owner = d;
+  t->owner_serial = d->serial;
   t->n_frames = n_frames;
-  t->grouped.resize((size_t)n_frames);
+  t->grouped = std::make_shared<std::vector<std::vector<cc_rect>>>((size_t)n_frames);
   t->sink = std::make_shared<BatchSink>();
-  cc_batch_ticket* raw = t.get();
+  std::shared_ptr<std::vector<std::vector<cc_rect>>> grouped = t->grouped;
   const int min_neighbors = p->min_neighbors;
-  t->sink->consume = [raw, min_neighbors](int f0, int nf, std::vector<CandOut>& cands) { group_pass(min_neighbors, f0, nf, cands, raw->grouped); };
+  t->sink->consume = [grouped, min_neighbors](int f0, int nf, std::vector<CandOut>& cands) { group_pass(min_neighbors, f0, nf, cands, *grouped); };
   t->sink->async_consume = true;  // passes of a batch cover disjoint frames: their helpers never touch the same entry of `grouped`
   st = run_batch(d, frames, on_device, n_frames, width, height, row_stride, frame_stride, p, true, false,
                  [](int, int, std::vector<CandOut>&) {}, /*defer_last=*/true, t->sink);
   if (st != CC_OK) {
-    if (d->pending.active && d->pending.sink == t->sink) {  // nothing may refer to the ticket once it is gone
+    if (d->pending.active && d->pending.sink == t->sink) {  // the batch failed: its unfetched pass delivers to nobody
       d->pending.active = false;
       d->pending.sink.reset();
     }
@@ -3401,26 +3584,35 @@ cc_status cc_detect_batch_submit(cc_detector* d, const uint8_t* frames, int on_d
   return CC_OK;
 }
 
+// A ticket is only ever ended by the detector it came from: with any other detector (or one that was destroyed and whose
+// address a new detector took over -- `serial` tells them apart) the call fails and the ticket stays valid.
+static bool ticket_is_of(const cc_detector* d, const cc_batch_ticket* t) { return d && t->owner == d && t->owner_serial == d->serial; }
+
 cc_status cc_detect_batch_collect(cc_detector* d, cc_batch_ticket* t, cc_rect* out, int cap, int32_t* offsets) {
   if (!t) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch_collect: null ticket");
-  std::unique_ptr<cc_batch_ticket> own(t);  // the ticket ends here, whatever happens
-  if (!d || t->owner != d) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch_collect: the ticket belongs to another detector");
+  if (!ticket_is_of(d, t)) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch_collect: the ticket belongs to another detector (it stays valid)");
+  std::unique_ptr<cc_batch_ticket> own(t);  // from here on the ticket ends with this call (except CC_ERR_BUFFER_TOO_SMALL)
   if (!offsets || (cap > 0 && !out) || cap < 0) {
     if (d->pending.active && d->pending.sink == t->sink) (void)retire_pending(d);
     return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch_collect: bad output buffers");
   }
   cc_status st = ensure_device(d->device);
-  if (st != CC_OK) return st;
+  if (st != CC_OK) {
+    (void)own.release();  // nothing was fetched: the caller may collect or discard again
+    return st;
+  }
   if (d->pending.active && d->pending.sink == t->sink) {  // its last pass has not been fetched by a later submit
     st = retire_pending(d);
     if (st != CC_OK) return st;
   }
   if (t->sink->status != CC_OK) return set_error(t->sink->status, "cc_detect_batch_collect: %s", t->sink->error.c_str());
-  t->sink->wait_jobs();  // the helper threads that sort + group what the passes delivered
+  st = wait_sink_jobs(*t->sink, "cc_detect_batch_collect");  // the helper threads that sort + group what the passes delivered
+  if (st != CC_OK) return st;
+  const std::vector<std::vector<cc_rect>>& grouped = *t->grouped;
   long long total = 0;
   for (int f = 0; f < t->n_frames; f++) {
     offsets[f] = (int32_t)total;
-    for (const cc_rect& r : t->grouped[(size_t)f]) {
+    for (const cc_rect& r : grouped[(size_t)f]) {
       if (total < cap) out[total] = r;
       total++;
     }
@@ -3435,14 +3627,22 @@ cc_status cc_detect_batch_collect(cc_detector* d, cc_batch_ticket* t, cc_rect* o
 
 cc_status cc_detect_batch_discard(cc_detector* d, cc_batch_ticket* t) {
   if (!t) return CC_OK;
+  if (!detector_registry(2, t->owner_serial)) {  // the owner was destroyed (it waited for the device and dropped the pass)
+    delete t;
+    return CC_OK;
+  }
+  if (!ticket_is_of(d, t)) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch_discard: the ticket belongs to another detector (it stays valid)");
   std::unique_ptr<cc_batch_ticket> own(t);
-  if (!d || t->owner != d) return set_error(CC_ERR_INVALID_ARG, "cc_detect_batch_discard: the ticket belongs to another detector");
   if (d->pending.active && d->pending.sink == t->sink) {  // let its last pass finish and drop what it delivers
     cc_status st = ensure_device(d->device);
-    if (st != CC_OK) return st;
+    if (st != CC_OK) {  // the pass cannot be fetched: cut it loose (its helper, if any, keeps `grouped` alive by itself)
+      d->pending.active = false;
+      d->pending.sink.reset();
+      return st;
+    }
     (void)retire_pending(d);
   }
-  t->sink->wait_jobs();
+  (void)wait_sink_jobs(*t->sink, "cc_detect_batch_discard");
   return CC_OK;
 }
 

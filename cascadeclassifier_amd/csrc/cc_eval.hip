@@ -613,6 +613,121 @@ static cc_status upload_indices(cc_evaluator* e, const int32_t* sample_idx, int 
 
 }  // namespace ccamd
 
+namespace ccamd {
+cc_status flush_pending_images(cc_evaluator* e) {
+  const int n = (int)e->pend_idx.size();
+  if (n == 0) return CC_OK;
+  const size_t px = (size_t)e->W * e->H;
+  // upload in sample order so that consecutive indices become one launch
+  std::vector<int> order((size_t)n);
+  for (int i = 0; i < n; i++) order[(size_t)i] = i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return e->pend_idx[(size_t)a] < e->pend_idx[(size_t)b]; });
+  CC_HIP(e->pin_in.ensure((size_t)n * px));
+  uint8_t* host = static_cast<uint8_t*>(e->pin_in.p);
+  for (int i = 0; i < n; i++) std::memcpy(host + (size_t)i * px, e->pend_px.data() + (size_t)order[(size_t)i] * px, px);
+  CC_HIP(e->d_imgs.ensure((size_t)n * px));
+  CC_HIP(hipMemcpyAsync(e->d_imgs.p, host, (size_t)n * px, hipMemcpyHostToDevice, e->stream));
+  const size_t lds = (size_t)e->H * (e->W + 1) * 4;
+  for (int i = 0; i < n;) {
+    int j = i + 1;
+    while (j < n && e->pend_idx[(size_t)order[(size_t)j]] == e->pend_idx[(size_t)order[(size_t)j - 1]] + 1) j++;
+    hipLaunchKernelGGL(k_set_images, dim3(j - i), dim3(64), lds, e->stream, e->d_imgs.p + (size_t)i * px, e->W, e->H,
+                       e->pend_idx[(size_t)order[(size_t)i]], e->d_sum.p, e->use_tilted ? e->d_tilted.p : nullptr, e->d_nf.p,
+                       e->type == CC_FEATURE_HAAR ? 1 : 0);
+    i = j;
+  }
+  CC_HIP(hipGetLastError());
+  CC_HIP(hipStreamSynchronize(e->stream));
+  for (int32_t idx : e->pend_idx) e->pend_slot[(size_t)idx] = -1;
+  e->pend_idx.clear();
+  e->pend_px.clear();
+  e->pend_n.store(0, std::memory_order_release);
+  return CC_OK;
+}
+
+// The integral(s) and the norm factor of one W x H window on the host, entry for entry what k_set_images writes
+// (haarfeatures.cpp:100-114, features.cpp:13-25, lbpfeatures.cpp:22-28): sum(y + 1, x + 1) = pixels above and to the left
+// incl.; tilted(Y, X) = pixels of rows y < Y within |x - (X - 1)| <= Y - y - 1; norm factor from the exact integer sums over
+// normrect (1, 1, W - 2, H - 2). Integer arithmetic throughout, one correctly rounded double sqrt at the end.
+static void host_window_integrals(const cc_evaluator* e, const uint8_t* px, std::vector<int32_t>& sum, std::vector<int32_t>& tilted, float& nf) {
+  const int W = e->W, H = e->H, sw = W + 1;
+  sum.assign((size_t)e->cols, 0);
+  for (int y = 0; y < H; y++) {
+    int acc = 0;
+    for (int x = 0; x < W; x++) {
+      acc += px[y * W + x];
+      sum[(size_t)(y + 1) * sw + x + 1] = sum[(size_t)y * sw + x + 1] + acc;
+    }
+  }
+  if (e->use_tilted) {
+    // row prefix sums r[y][x + 1] = px[y][0..x]; then the kernel's row-by-row clipped spans
+    std::vector<int32_t> rp((size_t)H * sw, 0);
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) rp[(size_t)y * sw + x + 1] = rp[(size_t)y * sw + x] + px[y * W + x];
+    tilted.assign((size_t)e->cols, 0);
+    for (int Y = 0; Y <= H; Y++)
+      for (int X = 0; X <= W; X++) {
+        int acc = 0;
+        for (int y = 0; y < Y; y++) {
+          const int half = Y - y - 1;
+          const int x0 = std::max(X - 1 - half, 0), x1 = std::min(X - 1 + half, W - 1);
+          if (x1 >= x0) acc += rp[(size_t)y * sw + x1 + 1] - rp[(size_t)y * sw + x0];
+        }
+        tilted[(size_t)Y * sw + X] = acc;
+      }
+  }
+  nf = 0.f;
+  if (e->type == CC_FEATURE_HAAR) {
+    long long sq = 0;
+    int sm = 0;
+    for (int y = 1; y < H - 1; y++)
+      for (int x = 1; x < W - 1; x++) {
+        const int p = px[y * W + x];
+        sm += p;
+        sq += p * p;
+      }
+    const double area = (double)((W - 2) * (H - 2));
+    nf = (float)std::sqrt((double)(area * (double)sq - (double)sm * (double)sm));
+  }
+}
+
+// operator()(fi) on the mirrored window: the expression of k_eval_list / k_eval_batch, operation for operation
+// (haarfeatures.h:108-122, lbpfeatures.h:70-83). This translation unit is compiled with -ffp-contract=off, and float
+// division on the host is the correctly rounded quotient the device kernels produce.
+static inline float host_mirror_value(const cc_evaluator* e, int fi) {
+  if (e->type == CC_FEATURE_HAAR) {
+    const HaarFeatDev& F = e->h_haar[(size_t)fi];
+    const int32_t* b = F.tilted ? e->mirror_tilted.data() : e->mirror_sum.data();
+    float ret = F.w[0] * (float)(b[F.p[0][0]] - b[F.p[0][1]] - b[F.p[0][2]] + b[F.p[0][3]]) +
+                F.w[1] * (float)(b[F.p[1][0]] - b[F.p[1][1]] - b[F.p[1][2]] + b[F.p[1][3]]);
+    if (F.w[2] != 0.0f) ret += F.w[2] * (float)(b[F.p[2][0]] - b[F.p[2][1]] - b[F.p[2][2]] + b[F.p[2][3]]);
+    const float nf = e->mirror_nf;
+    return nf == 0.0f ? 0.0f : ret / nf;
+  }
+  const int32_t* s = e->mirror_sum.data();
+  const LbpFeatDev& F = e->h_lbp[(size_t)fi];
+  int p[16];
+  for (int j = 0; j < 16; j++) p[j] = s[F.p[j]];
+  const int c = p[5] - p[6] - p[9] + p[10];
+  const int code = (p[0] - p[1] - p[4] + p[5] >= c ? 128 : 0) | (p[1] - p[2] - p[5] + p[6] >= c ? 64 : 0) |
+                   (p[2] - p[3] - p[6] + p[7] >= c ? 32 : 0) | (p[6] - p[7] - p[10] + p[11] >= c ? 16 : 0) |
+                   (p[10] - p[11] - p[14] + p[15] >= c ? 8 : 0) | (p[9] - p[10] - p[13] + p[14] >= c ? 4 : 0) |
+                   (p[8] - p[9] - p[12] + p[13] >= c ? 2 : 0) | (p[4] - p[5] - p[8] + p[9] >= c ? 1 : 0);
+  return (float)code;
+}
+static void host_catalog(cc_evaluator* e) {
+  std::call_once(e->host_catalog_once, [e]() {
+    if (e->type == CC_FEATURE_HAAR) {
+      e->h_haar.resize(e->haar.size());
+      for (size_t i = 0; i < e->h_haar.size(); i++) haar_to_dev(e->haar[i], e->W + 1, e->h_haar[i]);
+    } else {
+      e->h_lbp.resize((size_t)e->nfeat);
+      for (int i = 0; i < e->nfeat; i++) lbp_to_dev(&e->lbp[(size_t)i * 4], e->W + 1, e->h_lbp[(size_t)i]);
+    }
+  });
+}
+}  // namespace ccamd
+
 extern "C" {
 
 cc_status cc_debug_division_check(int device, uint64_t n_pairs, uint64_t seed, uint64_t* mismatches) {
@@ -736,6 +851,9 @@ cc_status cc_eval_set_images(cc_evaluator* e, const uint8_t* imgs, int n, int fi
   if (st != CC_OK) return st;
   if (n == 0) return CC_OK;
   std::lock_guard<std::mutex> lk(e->mu);
+  st = flush_pending_images(e);  // images set earlier, one at a time, must not land on top of these
+  if (st != CC_OK) return st;
+  if (e->mirror_idx >= first_idx && e->mirror_idx < first_idx + n) e->mirror_idx = -1;
   const size_t bytes = (size_t)n * e->W * e->H;
   CC_HIP(e->d_imgs.ensure(bytes));
   CC_HIP(hipMemcpyAsync(e->d_imgs.p, imgs, bytes, hipMemcpyHostToDevice, e->stream));
@@ -749,13 +867,42 @@ cc_status cc_eval_set_images(cc_evaluator* e, const uint8_t* imgs, int n, int fi
   return CC_OK;
 }
 
+// setImage for ONE window (haarfeatures.cpp:100-114, lbpfeatures.cpp:22-28) -- the call the trainer's negative-mining loop
+// makes for every candidate window (cascadeclassifier.cpp:340-347), 10^5..10^6 times per late stage, each followed by a
+// few operator() calls for the same sample. A launch per window would cost more than the window's arithmetic
+// (round 3: 15.7 k windows/s through two launches per window), so this call does no device work: it queues the pixels
+// (a later image for the same sample replaces the queued one; the queue goes to the device, runs of consecutive samples
+// per launch, before anything reads stored samples there) and keeps a host mirror of THIS window's integral(s) and norm
+// factor, from which cc_eval_calc / cc_eval_calc_list answer for this sample ("scalar, host-mirror fast
+// path"). The mirror's values are bit-identical to the device's (tests/test_gpu_eval.py compares every catalog feature).
 cc_status cc_eval_set_image(cc_evaluator* e, const uint8_t* img, size_t row_stride, uint8_t cls_label, int idx) {
   if (!e || !img) return set_error(CC_ERR_INVALID_ARG, "cc_eval_set_image: null argument");
   if (row_stride < (size_t)e->W) return set_error(CC_ERR_INVALID_ARG, "cc_eval_set_image: row stride smaller than the window width");
   if (idx < 0 || idx >= e->max_samples) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_set_image: idx %d out of range (%d)", idx, e->max_samples);
-  std::vector<uint8_t> packed((size_t)e->W * e->H);
-  for (int y = 0; y < e->H; y++) std::memcpy(&packed[(size_t)y * e->W], img + (size_t)y * row_stride, (size_t)e->W);
-  return cc_eval_set_images(e, packed.data(), 1, idx, &cls_label);
+  const size_t px = (size_t)e->W * e->H;
+  constexpr int kMaxQueued = 4096;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if ((int)e->pend_idx.size() >= kMaxQueued && (e->pend_slot.empty() || e->pend_slot[(size_t)idx] < 0)) {
+    cc_status st = eval_device(e);
+    if (st == CC_OK) st = flush_pending_images(e);
+    if (st != CC_OK) return st;
+  }
+  if (e->pend_slot.empty()) e->pend_slot.assign((size_t)e->max_samples, -1);
+  int slot = e->pend_slot[(size_t)idx];
+  if (slot < 0) {
+    slot = (int)e->pend_idx.size();
+    e->pend_idx.push_back(idx);
+    e->pend_px.resize((size_t)(slot + 1) * px);
+    e->pend_slot[(size_t)idx] = slot;
+    e->pend_n.store(slot + 1, std::memory_order_release);
+  }
+  uint8_t* dst = e->pend_px.data() + (size_t)slot * px;
+  for (int y = 0; y < e->H; y++) std::memcpy(dst + (size_t)y * e->W, img + (size_t)y * row_stride, (size_t)e->W);
+  e->mirror_idx = -1;
+  host_window_integrals(e, dst, e->mirror_sum, e->mirror_tilted, e->mirror_nf);
+  e->mirror_idx = idx;
+  e->cls[(size_t)idx] = (float)cls_label;
+  return CC_OK;
 }
 
 cc_status cc_eval_calc_batch(cc_evaluator* e, int fi_begin, int fi_end, const int32_t* sample_idx, int n_samples, float* out,
@@ -768,6 +915,7 @@ cc_status cc_eval_calc_batch(cc_evaluator* e, int fi_begin, int fi_end, const in
   if (st != CC_OK) return st;
   if (fi_begin == fi_end || n_samples == 0) return CC_OK;
   std::lock_guard<std::mutex> lk(e->mu);
+  if (cc_status fst = flush_pending_images(e); fst != CC_OK) return fst;  // images set one at a time reach the device first
   const int32_t* d_idx = nullptr;
   st = upload_indices(e, sample_idx, n_samples, &d_idx);
   if (st != CC_OK) return st;
@@ -800,6 +948,7 @@ cc_status cc_eval_calc_batch_device(cc_evaluator* e, int fi_begin, int fi_end, c
   if (st != CC_OK) return st;
   if (fi_begin == fi_end || n_samples == 0) return CC_OK;
   std::lock_guard<std::mutex> lk(e->mu);
+  if (cc_status fst = flush_pending_images(e); fst != CC_OK) return fst;  // images set one at a time reach the device first
   const int32_t* d_idx = nullptr;
   st = upload_indices(e, sample_idx, n_samples, &d_idx);
   if (st != CC_OK) return st;
@@ -835,6 +984,7 @@ cc_status cc_eval_calc_batch_sorted(cc_evaluator* e, int fi_begin, int fi_end, i
   const int nf = fi_end - fi_begin;
   if (nf == 0 || n_samples == 0) return CC_OK;
   std::lock_guard<std::mutex> lk(e->mu);
+  if (cc_status fst = flush_pending_images(e); fst != CC_OK) return fst;  // images set one at a time reach the device first
   const bool haar = e->type == CC_FEATURE_HAAR;
   const size_t total = (size_t)nf * n_samples;
   if (total > (size_t)INT32_MAX) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc_batch_sorted: block too large (%zu values); use smaller feature ranges", total);
@@ -879,6 +1029,12 @@ cc_status cc_eval_calc_batch_sorted(cc_evaluator* e, int fi_begin, int fi_end, i
 cc_status cc_eval_calc(cc_evaluator* e, int fi, int si, float* out) {
   if (!e || !out) return set_error(CC_ERR_INVALID_ARG, "cc_eval_calc: null argument");
   if (si < 0 || si >= e->max_samples) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc: sample %d out of range (%d)", si, e->max_samples);
+  if (si == e->mirror_idx) {  // the window set last by cc_eval_set_image: answered from its host mirror, no launch
+    if (fi < 0 || fi >= e->nfeat) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc: feature %d out of range (%d)", fi, e->nfeat);
+    host_catalog(e);
+    *out = host_mirror_value(e, fi);
+    return CC_OK;
+  }
   const int32_t idx = si;
   return cc_eval_calc_batch(e, fi, fi + 1, &idx, 1, out, 0);
 }
@@ -890,11 +1046,18 @@ cc_status cc_eval_calc_list(cc_evaluator* e, const int32_t* feature_idx, int n_f
   for (int i = 0; i < n_feats; i++)
     if (feature_idx[i] < 0 || feature_idx[i] >= e->nfeat)
       return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_calc_list: feature %d out of range (%d)", feature_idx[i], e->nfeat);
+  if (si == e->mirror_idx) {  // see cc_eval_calc
+    host_catalog(e);
+    for (int i = 0; i < n_feats; i++) out[i] = host_mirror_value(e, feature_idx[i]);
+    return CC_OK;
+  }
   cc_status st = eval_device(e);
   if (st != CC_OK) return st;
   if (n_feats == 0) return CC_OK;
   const bool haar = e->type == CC_FEATURE_HAAR;
   std::lock_guard<std::mutex> lk(e->mu);
+  st = flush_pending_images(e);
+  if (st != CC_OK) return st;
   if (haar && !e->d_haar_plain.p) {  // catalog with plain row offsets (row stride W + 1), built once
     std::vector<HaarFeatDev> dev(e->haar.size());
     for (size_t i = 0; i < dev.size(); i++) haar_to_dev(e->haar[i], e->W + 1, dev[i]);
@@ -949,6 +1112,7 @@ cc_status cc_eval_calc_custom_haar(cc_evaluator* e, const cc_haar_feature* feats
     haar_to_dev(f, e->W + 1, dev[i], e->S, e->use_tilted ? e->cols * e->S * 4 : 0);
   }
   std::lock_guard<std::mutex> lk(e->mu);
+  if (cc_status fst = flush_pending_images(e); fst != CC_OK) return fst;  // images set one at a time reach the device first
   const int32_t* d_idx = nullptr;
   st = upload_indices(e, sample_idx, n_samples, &d_idx);
   if (st != CC_OK) return st;
@@ -1016,6 +1180,9 @@ cc_status cc_eval_get_sample(cc_evaluator* e, int idx, int32_t* sum, int32_t* ti
   if (idx < 0 || idx >= e->max_samples) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_get_sample: idx %d out of range", idx);
   cc_status st = eval_device(e);
   if (st != CC_OK) return st;
+  std::lock_guard<std::mutex> lk(e->mu);
+  st = flush_pending_images(e);  // the device's copy is what this call reports, also for a sample set a moment ago
+  if (st != CC_OK) return st;
   if (sum) CC_HIP(hipMemcpy(sum, e->d_sum.p + (size_t)idx * e->cols, (size_t)e->cols * 4, hipMemcpyDeviceToHost));
   if (tilted) {
     if (!e->use_tilted) return set_error(CC_ERR_INVALID_ARG, "cc_eval_get_sample: evaluator keeps no tilted integrals (mode != ALL)");
@@ -1040,6 +1207,7 @@ cc_status cc_eval_predict_cascade(cc_evaluator* e, const cc_cascade* c, const in
   if (st != CC_OK) return st;
   if (n_samples == 0) return CC_OK;
   std::lock_guard<std::mutex> lk(e->mu);
+  if (cc_status fst = flush_pending_images(e); fst != CC_OK) return fst;  // images set one at a time reach the device first
   const int32_t* d_idx = nullptr;
   st = upload_indices(e, sample_idx, n_samples, &d_idx);
   if (st != CC_OK) return st;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -72,6 +73,9 @@ hipError_t sort_rows_block(const float* vals, int rows, int n, float* keys_out, 
 
 cc_status launch_batch(cc_evaluator* e, bool haar, const void* feats, int fb, int fe, const int32_t* d_idx, int ns,
                        float* d_out_ptr, int normalized, size_t out_pitch /* 0 = n_samples */);
+// Sends the images queued by cc_eval_set_image to the device (runs of consecutive sample indices, one launch per run).
+// Every entry point that reads stored samples on the device calls it first. Caller holds e->mu.
+cc_status flush_pending_images(cc_evaluator* e);
 
 }  // namespace ccamd
 
@@ -115,6 +119,21 @@ struct cc_evaluator {
   EBuf<double> d_split_tab, d_split_out;
   EBuf<int32_t> d_split_idx;
   ccamd::PinnedBuf pin_in, pin_out;
+  // ---- single-image path (cc_eval_set_image / cc_eval_calc / cc_eval_calc_list), see cc_eval.hip ----
+  // images set one at a time that the device has not seen yet: pixels (W * H each), sample index, and where a sample's
+  // latest image sits in the queue (pend_slot[idx], -1 = not queued); guarded by mu
+  std::vector<uint8_t> pend_px;
+  std::vector<int32_t> pend_idx;
+  std::vector<int32_t> pend_slot;
+  std::atomic<int> pend_n{0};
+  // host mirror of the sample set LAST by cc_eval_set_image: its integral(s) and norm factor, computed on the host with the
+  // device kernels' arithmetic; answers cc_eval_calc / cc_eval_calc_list for that sample without a launch
+  int mirror_idx = -1;
+  std::vector<int32_t> mirror_sum, mirror_tilted;
+  float mirror_nf = 0.f;
+  std::once_flag host_catalog_once;
+  std::vector<HaarFeatDev> h_haar;  // catalog with plain fastRect offsets (row stride W + 1)
+  std::vector<LbpFeatDev> h_lbp;
   ~cc_evaluator() {
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);

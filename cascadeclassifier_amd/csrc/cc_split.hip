@@ -293,6 +293,180 @@ __global__ __launch_bounds__(1024) void k_split_ord(SplitOrdArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same search, re-shaped in round 4 for the case the LDS table of 8-byte entries covers (TAB 2 above: +-1 responses or
+// class labels, <= 20 480 samples -- every node of a cascade stage): straight-line code with ONE rare branch per rank.
+// Counters of k_split_ord at configs[4] (profiles/r04_training_kernels.txt): the block-per-CU launch gives a SIMD 2.5
+// wavefronts, each of which walks 20 000 ranks through four divergent branches per rank (membership, value change,
+// candidate, record) -- 6 s_cbranch per rank, 45 vector instructions, one issued every ~6.5 cycles: neither memory (34 %
+// of HBM) nor the LDS (10 % busy) limits it, the branch bubbles and the instruction count of a lone wavefront do.
+// Here
+//  * a sample outside the node adds +0.0 to every running sum (exact: the sums start at +0 / are only ever decreased by
+//    +0) and is kept out of `count`, `prev` and the value-change test by its mask bit: no membership branch;
+//  * the quality's numerator / denominator and the "cannot beat the record" test are computed for every rank; only a
+//    lane that may set a record enters the one branch, which holds the division and the record update;
+//  * the record's threshold best * (1 - 2^-50) is kept beside the record instead of being recomputed per rank (one
+//    multiplication less; the test stays a sufficient condition: num < fl(bt * den), bt = fl(best (1 - 2^-50)), den > 0,
+//    best > 0 imply num / den < best, hence fl(num / den) <= best);
+//  * the loads of the next 16 ranks are issued before the current 16 are consumed.
+// Operation order of every sum and of the quality expression is the reference's (o_cvboostree.cpp:361-426, :192-238).
+// ------------------------------------------------------------------------------------------------
+constexpr int SPLIT_LEAN_WAVES = 12;  // wavefronts per block at most: 3 per SIMD, i.e. 168 VGPRs for the two chunks of table reads in flight
+constexpr int SPLIT_TABLE_PAD_RANKS = 64;  // the sorted tables are allocated (and zeroed) this many ranks beyond the last group's end:
+                                           // the lean kernel reads up to 3 chunks ahead without bounds checks
+template <int MODE, class TI>
+__global__ __launch_bounds__(64 * SPLIT_LEAN_WAVES) void k_split_ord_lean(SplitOrdArgs A) {
+  extern __shared__ double l_tab[];
+  const int lane = threadIdx.x & 63;
+  const int group = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  {
+    const double* src = reinterpret_cast<const double*>(A.tab);
+    for (int i = threadIdx.x; i < A.n_pre; i += blockDim.x) l_tab[i] = src[i];
+    __syncthreads();
+  }
+  if (group >= A.n_groups) return;
+  const int f = group * 64 + lane;
+  const size_t base = (size_t)group * A.n_pre * 64 + lane;
+  const float* sv = A.sv + base;
+  const TI* si = reinterpret_cast<const TI*>(A.si) + base;
+  const float epsilon = FLT_EPSILON * 2;
+  constexpr unsigned NOT_IN_NODE_HI = 0x7ff80000u;  // high word of the quiet NaN the host writes for samples outside the node (low word 0)
+  double L = 0, R, lsum = 0, rsum = 0, lcw0 = 0, lcw1 = 0, rcw0 = A.w_total0, rcw1 = A.w_total1;
+  if (MODE == 0) {
+    R = A.w_total0;
+    rsum = A.rsum0;
+  } else {
+    R = rcw0 + rcw1;
+    rsum = rcw0 * rcw0 + rcw1 * rcw1;  // rsum2; lsum plays lsum2
+  }
+  double best_val = -1.0;
+  double bt = -HUGE_VAL;  // best_val * (1 - 2^-50) once best_val > 0; -inf before: every value change is a candidate
+  int best_i = -1, count = 0;
+  float prev = 0.f, vl = 0.f, vr = 0.f;
+  constexpr int U = CC_SPLIT_UNROLL;
+  static_assert(3 * U <= SPLIT_TABLE_PAD_RANKS, "table padding covers the read-ahead");
+  float va[U], vb[U];
+  unsigned sa[U], sb[U];
+  auto load = [&](int r0, float (&vv)[U], unsigned (&ss)[U]) {  // no bounds checks: see SPLIT_TABLE_PAD_RANKS
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      vv[k] = sv[(size_t)(r0 + k) * 64];
+      ss[k] = (unsigned)si[(size_t)(r0 + k) * 64];
+    }
+  };
+  // A chunk is consumed in blocks of B ranks: the running sums, the quality's numerator / denominator and the "cannot beat
+  // the record" test of the B ranks are straight-line code (the B evaluations are independent chains the scheduler can
+  // interleave -- a branch per rank, as in k_split_ord, serialises them: the 4-deep dependent double chain plus the branch
+  // of one rank then sits in front of the next rank's), and ONE branch per block asks whether any lane has a candidate
+  // in any of the B ranks. Inside it the candidates are taken in rank order against the up-to-date record, exactly as the
+  // sequential loop does. The test in the straight-line part uses the record as of the block's start: an older (smaller)
+  // record only makes the test more conservative (more candidates), never wrong.
+  constexpr int B = 4;
+  static_assert(U % B == 0, "chunks are whole blocks");
+  auto process = [&](int r0, const float (&vv)[U], const unsigned (&ss)[U]) {
+    double x[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      unsigned g = A.dbg_nogather ? (unsigned)lane : ss[k];
+      g = g < (unsigned)A.n_pre ? g : 0u;  // ranks behind the last group's end carry padding
+      x[k] = l_tab[g];
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < U; k0 += B) {
+      double num[B], den[B];  // MODE 2: num = the quality itself
+      bool cand[B];
+      int cnt[B];
+      float pv[B];
+#pragma unroll
+      for (int j = 0; j < B; j++) {
+        const int k = k0 + j;
+        const unsigned long long xb = (unsigned long long)__double_as_longlong(x[k]);
+        const unsigned lo = (unsigned)xb, hi = (unsigned)(xb >> 32);
+        const bool member = (hi != NOT_IN_NODE_HI) & (r0 + k < A.n_pre);
+        const unsigned thi = member ? hi : 0u;  // outside the node: +0.0 (the marker's low word is 0)
+        const unsigned tlo = member ? lo : 0u;  // (read-ahead ranks may carry any entry)
+        const double w = __hiloint2double((int)(thi & 0x7fffffffu), (int)tlo);
+        const float val_k = vv[k];
+        const bool changed = member & (count > 0) & (prev + epsilon < val_k);
+        cnt[j] = count;
+        pv[j] = prev;
+        if (MODE == 2) {
+          const double a = lcw0 + rcw1, b = lcw1 + rcw0;
+          num[j] = a > b ? a : b;
+          den[j] = 1.0;
+          cand[j] = changed & (best_val < num[j]);
+        } else {
+          num[j] = MODE == 0 ? lsum * lsum * R + rsum * rsum * L : lsum * R + rsum * L;
+          den[j] = L * R;
+          // anything but "den > 0 and provably below the record" takes the division (incl. den <= 0, NaN), as k_split_ord does
+          cand[j] = changed & !((den[j] > 0.0) & (num[j] < bt * den[j]));
+        }
+        if (MODE == 0) {
+          const double t = __hiloint2double((int)thi, (int)tlo);  // response * w, sign included
+          L += w;
+          R -= w;
+          lsum += t;
+          rsum -= t;
+        } else {
+          const bool c1 = (int)thi < 0;  // class 1 carries the sign bit
+          if (MODE == 1) {
+            const double w2 = w * w;
+            L += w;
+            R -= w;
+            const double lv = c1 ? lcw1 : lcw0, rv = c1 ? rcw1 : rcw0;
+            lsum += 2 * lv * w + w2;
+            rsum -= 2 * rv * w - w2;
+            const double nl = lv + w, nr = rv - w;
+            lcw1 = c1 ? nl : lcw1;
+            rcw1 = c1 ? nr : rcw1;
+            lcw0 = c1 ? lcw0 : nl;
+            rcw0 = c1 ? rcw0 : nr;
+          } else {
+            const double w1 = c1 ? w : 0.0, w0 = c1 ? 0.0 : w;
+            lcw1 += w1;
+            rcw1 -= w1;
+            lcw0 += w0;
+            rcw0 -= w0;
+          }
+        }
+        prev = member ? val_k : prev;
+        count += member ? 1 : 0;
+      }
+      bool any = cand[0];
+#pragma unroll
+      for (int j = 1; j < B; j++) any |= cand[j];
+      if (__builtin_expect(any, 0)) {
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+          if (cand[j]) {
+            const double val = MODE == 2 ? num[j] : num[j] / den[j];
+            if (best_val < val) {
+              best_val = val;
+              if (MODE != 2) bt = val > 0.0 ? val * (1.0 - 0x1p-50) : -HUGE_VAL;
+              best_i = cnt[j] - 1;
+              vl = pv[j];
+              vr = vv[k0 + j];
+            }
+          }
+        }
+      }
+    }
+  };
+  load(0, va, sa);
+  for (int r0 = 0; r0 < A.n_pre; r0 += 2 * U) {  // two chunks per trip: the next chunk's table reads fly while one is consumed
+    load(r0 + U, vb, sb);
+    process(r0, va, sa);
+    load(r0 + 2 * U, va, sa);
+    process(r0 + U, vb, sb);
+  }
+  if (f < A.n_vars) {
+    A.best_val[f] = best_val;
+    A.best_i[f] = best_i;
+    A.best_vl[f] = vl;
+    A.best_vr[f] = vr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Categorical variables (LBP, 256 categories): one block per variable, one thread per category; the node's samples are
 // streamed through LDS in node order and every thread adds the samples of its own category, i.e. each category's sums
 // are accumulated in the reference's order (o_cvboostree.cpp:456-464 regression, :283-288 classification).
@@ -355,6 +529,8 @@ cc_status cc_eval_presort_range(cc_evaluator* e, int fi_begin, int fi_end, int n
   cc_status st = eval_device(e);
   if (st != CC_OK) return st;
   std::lock_guard<std::mutex> lk(e->mu);
+  st = flush_pending_images(e);
+  if (st != CC_OK) return st;
   e->presort_n = 0;
   const bool haar = e->type == CC_FEATURE_HAAR;
   const int F = fi_end - fi_begin, N = n_samples;
@@ -389,11 +565,18 @@ cc_status cc_eval_presort_range(cc_evaluator* e, int fi_begin, int fi_end, int n
     return CC_OK;
   }
   const bool idx16 = N <= 65536;
-  CC_HIP(e->d_sorted_val.ensure(groups * 64 * (size_t)N));
-  if (idx16)
-    CC_HIP(e->d_sorted_idx16.ensure(groups * 64 * (size_t)N));
-  else
-    CC_HIP(e->d_sorted_idx32.ensure(groups * 64 * (size_t)N));
+  {  // tables + SPLIT_TABLE_PAD_RANKS ranks of zeroed padding behind the last group (read-ahead of k_split_ord_lean)
+    const size_t used = groups * 64 * (size_t)N, pad = (size_t)SPLIT_TABLE_PAD_RANKS * 64;
+    CC_HIP(e->d_sorted_val.ensure(used + pad));
+    CC_HIP(hipMemsetAsync(e->d_sorted_val.p + used, 0, pad * sizeof(float), e->stream));
+    if (idx16) {
+      CC_HIP(e->d_sorted_idx16.ensure(used + pad));
+      CC_HIP(hipMemsetAsync(e->d_sorted_idx16.p + used, 0, pad * sizeof(uint16_t), e->stream));
+    } else {
+      CC_HIP(e->d_sorted_idx32.ensure(used + pad));
+      CC_HIP(hipMemsetAsync(e->d_sorted_idx32.p + used, 0, pad * sizeof(int32_t), e->stream));
+    }
+  }
   EBuf<float> keys_out;
   EBuf<int> iota, sorted, offsets;
   EBuf<char> temp;
@@ -537,6 +720,7 @@ cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, in
     A.dbg_nogather = std::getenv("CCAMD_DEBUG_SPLIT_NOGATHER") ? 1 : 0;
     // wavefronts per block: with the table in LDS one block owns a CU, so spread the groups evenly over the CUs
     // (162 336 variables = 2 537 groups -> 254 blocks of 10 wavefronts on 256 CUs); from global memory, one wavefront
+    static const bool lean = std::getenv("CCAMD_SPLIT_BRANCHY") == nullptr;  // A/B: the round-1 kernel for the 8-byte LDS table
     int wpb = 1;
     if (tab_kind != 0) {
       hipDeviceProp_t prop;
@@ -544,6 +728,7 @@ cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, in
       const int cus = std::max(1, prop.multiProcessorCount);
       wpb = (int)std::min<size_t>(16, std::max<size_t>(1, (groups + cus - 1) / cus));
       if (const char* v = std::getenv("CCAMD_SPLIT_WAVES")) wpb = std::max(1, std::min(16, std::atoi(v)));
+      if (tab_kind == 2 && lean) wpb = std::min(wpb, SPLIT_LEAN_WAVES);
     }
     const unsigned blocks = (unsigned)((groups + wpb - 1) / wpb);
     const size_t lds = tab_kind == 0 ? 0 : (size_t)N * entry_bytes;
@@ -554,12 +739,20 @@ cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, in
       CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_split_ord<M, TI, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((k_split_ord<M, TI, T>), dim3(blocks), dim3(64 * wpb), lds, e->stream, A);                             \
   } while (0)
+#define CC_LAUNCH_LEAN(M, TI)                                                                                                 \
+  do {                                                                                                                        \
+    if (lds > 64 * 1024)                                                                                                      \
+      CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_split_ord_lean<M, TI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_split_ord_lean<M, TI>), dim3(blocks), dim3(64 * wpb), lds, e->stream, A);                           \
+  } while (0)
 #define CC_LAUNCH_ORD2(M, TI)          \
   do {                                 \
     if (tab_kind == 0)                 \
       CC_LAUNCH_ORD3(M, TI, 0);        \
     else if (tab_kind == 1)            \
       CC_LAUNCH_ORD3(M, TI, 1);        \
+    else if (lean)                     \
+      CC_LAUNCH_LEAN(M, TI);           \
     else                               \
       CC_LAUNCH_ORD3(M, TI, 2);        \
   } while (0)
@@ -577,6 +770,7 @@ cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, in
     else
       CC_LAUNCH_ORD(2);
 #undef CC_LAUNCH_ORD
+#undef CC_LAUNCH_LEAN
 #undef CC_LAUNCH_ORD2
 #undef CC_LAUNCH_ORD3
     (void)hipEventRecord(e->ev_b, e->stream);

@@ -161,8 +161,11 @@ CC_API cc_status cc_detect_batch_device_only(cc_detector* d, const uint8_t* fram
  * the ticket until collect. Frames (device or host memory) must stay valid until the batch is collected. collect frees
  * the ticket, except when it returns CC_ERR_BUFFER_TOO_SMALL (offsets[n_frames] then holds the count: collect again with
  * room for it). cc_detect_batch_discard ends a ticket whose results are not wanted (it waits for the batch's last pass;
- * NULL is accepted); a ticket that is neither collected nor discarded leaks. No reference counterpart (the reference
- * handles one image per call, tools/detection/Cpp/main.cpp:42-45). */
+ * NULL is accepted); a ticket that is neither collected nor discarded leaks. A ticket is ended only by the detector that
+ * issued it: collect / discard with another detector return CC_ERR_INVALID_ARG and leave the ticket valid (collect it
+ * with its own detector); after its detector has been destroyed a ticket can only be discarded (with any detector
+ * argument, NULL included), collecting it is CC_ERR_INVALID_ARG. No reference counterpart (the reference handles one
+ * image per call, tools/detection/Cpp/main.cpp:42-45). */
 typedef struct cc_batch_ticket cc_batch_ticket;
 CC_API cc_status cc_detect_batch_submit(cc_detector* d, const uint8_t* frames, int on_device, int n_frames, int width,
                                         int height, size_t row_stride, size_t frame_stride, const cc_detect_params* p,

@@ -96,6 +96,20 @@ int main() {
   // 5. another evaluator on the same thread forgets everything
   EXPECT(ix.access(1, 0, uid + 1, 1, 3, F) == ValueCacheIndex::MISS_ROW);
   EXPECT(ix.list.empty());
+  // 6. a miss whose evaluation fails leaves no cached claim behind (round-3 advisor finding): the next access of the same
+  //    feature / sample is a miss again, for rows and for lists, and the learned list keeps its features
+  {
+    ValueCacheIndex jx;
+    EXPECT(jx.access(7, 0, 99, 1, /*last_set=*/-1, F) == ValueCacheIndex::MISS_ROW);
+    jx.evaluation_failed();
+    EXPECT(jx.access(7, 1, 99, 1, -1, F) == ValueCacheIndex::MISS_ROW);  // without the hook this would be HIT_ROW on an empty row
+    EXPECT(jx.access(7, 2, 99, 1, -1, F) == ValueCacheIndex::HIT_ROW);
+    EXPECT(jx.access(11, 4, 99, 2, /*last_set=*/4, F) == ValueCacheIndex::MISS_LIST);
+    jx.evaluation_failed();
+    EXPECT(jx.access(11, 4, 99, 2, 4, F) == ValueCacheIndex::MISS_LIST);  // not HIT_LIST on values that were never produced
+    EXPECT(jx.list.size() == 1 && jx.list[0] == 11);
+    EXPECT(jx.access(11, 4, 99, 2, 4, F) == ValueCacheIndex::HIT_LIST);
+  }
   if (failures) return 1;
   std::printf("test_cache_policy OK\n");
   return 0;

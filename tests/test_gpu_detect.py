@@ -4,6 +4,8 @@ BIT-EXACT; Haar stage sums are compared exactly too (tolerance 0.0: the kernels 
 FMA contraction off, float feature values and a double accumulator), see HAAR_SUM_TOL."""
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -288,3 +290,68 @@ def test_submit_collect_pipelines_batches_with_identical_results(haar_xml, lbp_x
     for t in (t8, t9):
         got = r.detect_batch_collect(t)
         assert all(x.shape == y.shape and (x == y).all() for x, y in zip(got, wl))
+
+
+def test_tickets_are_ended_only_by_their_own_detector(haar_xml):
+    """Round-3 advisor finding: collect / discard used to free the ticket before checking whose it was, while the owner's
+    unfetched pass still delivered into it. Now a ticket handed to the wrong detector stays valid (the call fails), its
+    own detector can still collect it, the owner keeps working, and after the owner is gone the ticket can only be
+    discarded -- with results checked against the oracle, not against another run of the library."""
+    a = np.stack([frame_natural(320, 200, 400 + i) for i in range(5)])
+    o = orc.load_cascade_xml(haar_xml)
+    want = [orc.detect_multiscale(o, a[i], 1.1, 2, nthreads=4) for i in range(5)]
+    p, q = cc.CascadeClassifier(haar_xml, max_batch=8), cc.CascadeClassifier(haar_xml, max_batch=8)
+    q.detect_batch(a[:1], 1.1, 2)  # q has a live detector handle too
+    t1 = p.detect_batch_submit(a, 1.1, 2)
+    out, offs = np.zeros((1024, 4), np.int32), np.zeros(6, np.int32)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert L.lib().cc_detect_batch_collect(q._detector(), t1["ticket"], vp(out), 1024, vp(offs)) == L.CC_ERR_INVALID_ARG
+    assert L.lib().cc_detect_batch_discard(q._detector(), t1["ticket"]) == L.CC_ERR_INVALID_ARG
+    t2 = p.detect_batch_submit(a, 1.1, 2)  # the owner retires t1's pending pass into the (still valid) ticket
+    for t in (t1, t2):
+        got = p.detect_batch_collect(t)
+        for i in range(5):
+            x, y = got[i][np.lexsort(got[i].T[::-1])], want[i][np.lexsort(want[i].T[::-1])]
+            assert x.shape == y.shape and (x == y).all()
+    # the owner is destroyed with a batch outstanding: collecting is an error, discarding (with any detector) frees it
+    t3 = p.detect_batch_submit(a, 1.1, 2)
+    raw = t3["ticket"]
+    p._release()
+    assert L.lib().cc_detect_batch_collect(q._detector(), raw, vp(out), 1024, vp(offs)) == L.CC_ERR_INVALID_ARG
+    assert L.lib().cc_detect_batch_discard(q._detector(), raw) == L.CC_OK
+    got = q.detect_batch(a, 1.1, 2)
+    assert all(x.shape == y.shape for x, y in zip(got, want))
+
+
+def test_host_frames_go_through_the_pinned_staging_area(haar_xml, monkeypatch):
+    """Host frames are copied into the detector's pinned staging area and sent with one asynchronous copy per pass
+    (round 4): strided frames, a batch that grows the staging areas while a pass of a smaller batch is still unfetched and
+    has to be REDONE from its staged frames (candidate-list overflow: the round-3 advisor's second finding), pinned caller
+    memory (no staging copy) and the round-3 path (CCAMD_NO_PINNED_STAGING) all give the oracle's rectangles."""
+    import torch
+    o = orc.load_cascade_xml(haar_xml)
+    big = np.stack([frame_natural(360, 240, 500 + i) for i in range(12)])
+    want = [orc.detect_multiscale(o, big[i], 1.1, 2, nthreads=4) for i in range(12)]
+
+    def same(got, idx):
+        assert len(got) == len(idx)
+        for g, i in zip(got, idx):
+            x, y = g[np.lexsort(g.T[::-1])], want[i][np.lexsort(want[i].T[::-1])]
+            assert x.shape == y.shape and (x == y).all(), i
+    monkeypatch.setenv("CCAMD_CAND_CAP", "16")  # every pass overflows its candidate list once and is redone
+    p = cc.CascadeClassifier(haar_xml, max_batch=16)
+    t1 = p.detect_batch_submit(big[:3], 1.1, 2)      # small staging areas, last pass left pending
+    t2 = p.detect_batch_submit(big, 1.1, 2)          # larger passes: the staging areas grow under the pending pass
+    same(p.detect_batch_collect(t1), range(3))
+    same(p.detect_batch_collect(t2), range(12))
+    monkeypatch.delenv("CCAMD_CAND_CAP")
+    q = cc.CascadeClassifier(haar_xml, max_batch=16)
+    same(q.detect_batch(big, 1.1, 2), range(12))
+    pinned = torch.from_numpy(big).pin_memory()
+    same(q.detect_batch(pinned.numpy(), 1.1, 2), range(12))  # pinned caller memory: asynchronous copies straight from it
+    tk = [q.detect_batch_submit(big[i:i + 4], 1.1, 2) for i in (0, 4, 8)]
+    for k, t in enumerate(tk):
+        same(q.detect_batch_collect(t), range(4 * k, 4 * k + 4))
+    monkeypatch.setenv("CCAMD_NO_PINNED_STAGING", "1")
+    r = cc.CascadeClassifier(haar_xml, max_batch=16)
+    same(r.detect_batch(big, 1.1, 2), range(12))

@@ -4,6 +4,8 @@ the rest compares bulk evaluation with the oracle. LBP codes, integrals and Feat
 operator() values (one float division by the norm factor) are compared exactly as well (tolerance 0)."""
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -330,6 +332,52 @@ def test_feature_list_of_one_sample_matches_the_bulk_values(ftype, mode):
         e.calc_list([F], 0)
     with pytest.raises(cc.CascadeError):
         e.calc_list([0], 6)
+
+
+@pytest.mark.parametrize("ftype,mode", [(ev.HAAR, ev.ALL), (ev.HAAR, ev.BASIC), (ev.LBP, 0)])
+def test_host_mirror_of_the_last_set_window_equals_the_device(ftype, mode):
+    """Round 4: cc_eval_set_image queues the window for the device and mirrors it on the host; cc_eval_calc /
+    cc_eval_calc_list for THAT sample are answered from the mirror (no launch: the trainer's negative-mining loop makes
+    these calls per window, cascadeclassifier.cpp:340-347). The mirror must give the device's bits for EVERY catalog
+    feature (upright, tilted, LBP), its integrals / norm factor must be the device's, a flat window must give the nf == 0
+    short-circuit, and a later image for the same or another sample must supersede it in the right order."""
+    rng = np.random.default_rng(17)
+    e = cc.CvFeatureEvaluator.create(ftype)
+    e.init(cc.CvFeatureParams(ftype, mode), 5, (24, 24))
+    F = e.getNumFeatures()
+    allf = np.arange(F, dtype=np.int32)
+    imgs = rng.integers(0, 256, (4, 24, 24), dtype=np.uint8)
+    imgs[2] = 77  # flat: Haar norm factor 0
+    for k, idx in enumerate((3, 3, 0, 4)):  # same slot twice (the loop's shape), then other slots
+        padded = np.zeros((24, 40), np.uint8)
+        padded[:, :24] = imgs[k]
+        view = padded[:, :24]  # row stride 40: setImage takes strided windows
+        L.check(L.lib().cc_eval_set_image(e._e, view.ctypes.data_as(C.c_void_p), 40, k & 1, idx))
+        assert e.getCls(idx) == float(k & 1)
+        host = e.calc_list(allf, idx)                 # mirror
+        one = np.array([e(int(f), idx) for f in (0, F // 2, F - 1)], np.float32)
+        dev = e.calc_batch(0, F, sample_idx=[idx])[:, 0]  # device (the queued image is flushed first)
+        assert (host.view(np.uint32) == dev.view(np.uint32)).all(), (k, idx)
+        assert (one.view(np.uint32) == dev[[0, F // 2, F - 1]].view(np.uint32)).all()
+        if ftype == ev.HAAR and k == 2:
+            assert (host == 0).all()
+    # what the device holds after all that: slot 3 = image 1 (the later of the two), slot 0 = image 2, slot 4 = image 3
+    if ftype == ev.HAAR:
+        s, t, nf = orc.set_images(imgs, want_tilted=mode == ev.ALL)
+    else:
+        s, t, nf = orc.set_images(imgs, want_norm=False)
+    for idx, k in ((3, 1), (0, 2), (4, 3)):
+        got = e.get_sample(idx)
+        assert (got[0] == s[k]).all()
+        if ftype == ev.HAAR:
+            assert got[2] == nf[k]
+            if mode == ev.ALL:
+                assert (got[1] == t[k]).all()
+    # setImages over a mirrored slot drops the mirror
+    e.setImage(imgs[0], 1, 2)
+    e.setImages(imgs[1:2], first_idx=2)
+    assert (e.calc_list(allf, 2).view(np.uint32) == e.calc_batch(0, F, sample_idx=[2])[:, 0].view(np.uint32)).all()
+    assert (e.get_sample(2)[0] == s[1]).all()
 
 
 def test_bulk_values_into_pitched_device_memory():

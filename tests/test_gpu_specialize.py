@@ -121,6 +121,26 @@ def test_stage_groups_do_not_change_results(lbp_xml, haar_xml, budget, monkeypat
         assert n > 0
 
 
+@pytest.mark.parametrize("dense_from,group_stumps,wave_below", [(1, 0, 24), (2, 20, 24), (3, 12, 8), (2, 10, 0), (0, 20, 24)])
+def test_queue_form_does_not_change_results(lbp_xml, haar_xml, dense_from, group_stumps, wave_below, monkeypatch):
+    """Round 4: from stage group CCAMD_DENSE_FROM on the block's queue is a plain list (wave-aggregated append) instead
+    of the bank-class table. Which form a group reads must not change a code, exit stage, stage sum or rectangle:
+    table-driven and specialised kernels, LBP (where the list is the default from stage 2) and Haar, together with the
+    wave-phase threshold and the stage-group budget (the three knobs meet in the same queue)."""
+    monkeypatch.setenv("CCAMD_DENSE_FROM", str(dense_from))
+    monkeypatch.setenv("CCAMD_GROUP_STUMPS", str(group_stumps))
+    monkeypatch.setenv("CCAMD_WAVE_BELOW", str(wave_below))
+    img, img2 = frame_natural(640, 360, 21), frame_uniform(300, 200, 22)
+    for xml, k in ((lbp_xml, 20), (haar_xml, 4)):
+        o = orc.load_cascade_xml(xml)
+        p = cc.CascadeClassifier(xml)
+        n = _same_as_oracle(p, o, img, 1.1)  # table-driven
+        assert p.specialize(k) == k
+        n += _same_as_oracle(p, o, img, 1.1)
+        n += _same_as_oracle(p, o, img2, 1.25)
+        assert n > 0
+
+
 def test_noinline_generated_stages_match(lbp_xml, haar_xml, monkeypatch):
     """CCAMD_SPEC_NOINLINE=1: the generated stages as one real function instead of a copy per call site."""
     monkeypatch.setenv("CCAMD_SPEC_NOINLINE", "1")
