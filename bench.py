@@ -214,7 +214,110 @@ def spawn_ranks(n):
                 for q in alive:
                     procs[q].terminate()
         time.sleep(0.05)
+    print("[bench] rank exit codes: " + json.dumps([p.returncode for p in procs]), file=sys.stderr)
     return status
+
+
+def setup_gather(args, rank, world, dev_index, comm_dev):
+    """N > 1: the gather of detections runs on the C ABI's own RCCL communicator (cc_comm_* / cc_gather_detections, what a
+    C++ host uses); torch.distributed only carries the 128-byte unique id to the other ranks. The torch collective with
+    the same protocol stays as the fallback (and is what the gloo rehearsal on a one-GPU box uses). Returns (comm or None,
+    description). Touches no GPU by itself (the RCCL transport does, the loopback TCP one does not)."""
+    import torch
+    import torch.distributed as dist
+
+    from cascadeclassifier_amd.distributed import gather_detections
+    comm = None
+    gather_kind = "none (single rank)"
+    if world > 1:
+        gather_kind = f"torch.distributed all_gather ({args.backend})"
+        # (CCAMD_COMM_TRANSPORT=tcp: the same C-ABI calls over the library's loopback transport -- the rehearsal of this leg
+        # on a one-GPU box, where RCCL refuses two ranks on one device)
+        tcp = os.environ.get("CCAMD_COMM_TRANSPORT") == "tcp"
+        if (args.backend == "nccl" or tcp) and not os.environ.get("CCAMD_BENCH_TORCH_GATHER"):
+            from cascadeclassifier_amd.distributed import Comm
+            ok = torch.zeros(1, dtype=torch.int32, device=comm_dev)
+            try:
+                comm = Comm.from_torch(dev_index)
+                ok += 1
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: cc_comm_create failed ({e}); gathering with torch.distributed", file=sys.stderr)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks or none
+            if int(ok.item()) == 1:
+                # one trial gather before anything is timed: the C ABI's collective has run on CPU transports and on one rank
+                # only (no multi-GPU box so far); if it fails on any rank, every rank falls back to the torch collective
+                ok.fill_(0)
+                try:
+                    trial = gather_detections([np.array([[rank, 0, 1, 1]], np.int32)], device=comm_dev, comm=comm)
+                    if len(trial) == world and all(len(t) == 1 and int(t[0][0]) == r for r, t in enumerate(trial)):
+                        ok += 1
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench] rank {rank}: cc_gather_detections failed ({e}); gathering with torch.distributed", file=sys.stderr)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                gather_kind = "cc_gather_detections (C ABI, " + ("loopback TCP transport" if tcp else "RCCL ncclAllGather x2") + ")"
+            else:
+                if comm is not None:
+                    try:
+                        comm.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+                comm = None
+    return comm, gather_kind
+
+
+def rehearse_gather(args):
+    """`--rehearse-gather`: the N > 1 leg of this script without a detector and without a GPU -- what can be run of BASELINE
+    configs[3] (8 ranks x 64 frames) where there is no 8-GPU node. Every rank makes up the rectangles of its frames (frame f
+    gets f % 7 rectangles derived from f; one rank has none), the ranks rendezvous, build the communicator, run the trial
+    gather and `--steps` timed gathers with the barriers and the max-over-ranks reduction of the real run, and every rank
+    checks that it holds all frames' rectangles in frame order. Rank 0 prints ONE line; it carries no `metric` / `value`."""
+    import torch
+    import torch.distributed as dist
+
+    from cascadeclassifier_amd.distributed import gather_detections
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    assert args.backend != "nccl", "--rehearse-gather runs without GPUs: use --backend gloo"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend)
+    comm_dev = torch.device("cpu")
+    comm, gather_kind = setup_gather(args, rank, world, 0, comm_dev)
+    B = args.frames
+
+    def fake(f, owner):
+        k = 0 if owner == world - 3 else f % 7
+        return np.array([[f, j, 24 + j, 24 + f % 5] for j in range(k)], np.int32).reshape(-1, 4)
+    mine = [fake(rank * B + i, rank) for i in range(B)]
+    want = [fake(r * B + i, r) for r in range(world) for i in range(B)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+    ok = True
+    for _ in range(args.warmup):
+        gather_detections(mine, device=comm_dev, comm=comm)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = gather_detections(mine, device=comm_dev, comm=comm)
+        ok = ok and len(got) == len(want) and all(a.shape == b.shape and (a == b).all() for a, b in zip(got, want))
+    sync()
+    dt = time.perf_counter() - t0
+    flag = torch.tensor([dt, 0.0 if ok else 1.0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if comm is not None:
+        comm.close()
+    if rank == 0:
+        print(json.dumps({"rehearsal": "gather of detections only: no detector, no GPU, made-up rectangles", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "frames_per_rank_per_step": B, "frames_per_step": B * world, "gather": gather_kind,
+                          "gather_ms_per_step": round(float(flag[0]) / max(args.steps, 1) * 1e3, 4),
+                          "every_rank_holds_all_frames_in_order": bool(flag[1] == 0.0)}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if float(flag[1]) == 0.0 else 4
 
 
 def main():
@@ -242,12 +345,17 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=5, help="repetitions of the CPU-baseline sample (median is reported)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--rehearse-gather", action="store_true", help="no detector, no GPU: every rank makes up the rectangles of its "
+                                                                   "--frames frames and the ranks run the N > 1 leg only (rendezvous, communicator, "
+                                                                   "trial gather, gathers, max-over-ranks timing); prints a line marked as a rehearsal")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` by itself: this process never touches the GPU; it starts one rank per GPU as child
         # processes (the env contract of torch.distributed.run) and exits with their status. Rank 0 prints the JSON line.
         sys.exit(spawn_ranks(args.gpus))
+    if args.rehearse_gather:
+        sys.exit(rehearse_gather(args))
 
     import torch
     import torch.distributed as dist
@@ -288,45 +396,7 @@ def main():
     chan_bytes = 8 if inf["feature_type"] == 0 else 4
     eval_bytes_per_frame = chan_bytes * integral_px  # every integral entry read exactly once
 
-    # N > 1: the gather of detections runs on the C ABI's own RCCL communicator (cc_comm_* / cc_gather_detections, what a
-    # C++ host uses); torch.distributed only carries the 128-byte unique id to the other ranks. The torch collective
-    # with the same protocol stays as the fallback (and is what the gloo rehearsal on a one-GPU box uses).
-    comm = None
-    gather_kind = "none (single rank)"
-    if world > 1:
-        gather_kind = f"torch.distributed all_gather ({args.backend})"
-        # (CCAMD_COMM_TRANSPORT=tcp: the same C-ABI calls over the library's loopback transport -- the rehearsal of this leg
-        # on a one-GPU box, where RCCL refuses two ranks on one device)
-        tcp = os.environ.get("CCAMD_COMM_TRANSPORT") == "tcp"
-        if (args.backend == "nccl" or tcp) and not os.environ.get("CCAMD_BENCH_TORCH_GATHER"):
-            from cascadeclassifier_amd.distributed import Comm
-            ok = torch.zeros(1, dtype=torch.int32, device=comm_dev)
-            try:
-                comm = Comm.from_torch(dev_index)
-                ok += 1
-            except Exception as e:  # noqa: BLE001
-                print(f"[bench] rank {rank}: cc_comm_create failed ({e}); gathering with torch.distributed", file=sys.stderr)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks or none
-            if int(ok.item()) == 1:
-                # one trial gather before anything is timed: the C ABI's collective has run on CPU transports and on one rank
-                # only (no multi-GPU box so far); if it fails on any rank, every rank falls back to the torch collective
-                ok.fill_(0)
-                try:
-                    trial = gather_detections([np.array([[rank, 0, 1, 1]], np.int32)], device=comm_dev, comm=comm)
-                    if len(trial) == world and all(len(t) == 1 and int(t[0][0]) == r for r, t in enumerate(trial)):
-                        ok += 1
-                except Exception as e:  # noqa: BLE001
-                    print(f"[bench] rank {rank}: cc_gather_detections failed ({e}); gathering with torch.distributed", file=sys.stderr)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 1:
-                gather_kind = "cc_gather_detections (C ABI, " + ("loopback TCP transport" if tcp else "RCCL ncclAllGather x2") + ")"
-            else:
-                if comm is not None:
-                    try:
-                        comm.close()
-                    except Exception:  # noqa: BLE001
-                        pass
-                comm = None
+    comm, gather_kind = setup_gather(args, rank, world, dev_index, comm_dev)
 
     def step():
         if args.device_only:

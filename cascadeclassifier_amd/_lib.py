@@ -112,6 +112,7 @@ SIGNATURES = {
     "cc_resize_linear_exact_u8": (_i, [_i, _vp, _i, _i, _sz, _vp, _i, _i, _sz]),
     "cc_debug_stream_dwords": (_i, [_i, _sz, _i, C.POINTER(C.c_uint32)]),
     "cc_debug_division_check": (_i, [_i, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cc_debug_vnf_check": (_i, [_i, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cc_group_rectangles": (_i, [_vp, _i, _i, _d, _vp, _i, C.POINTER(_i)]),
     "cc_eval_create": (_i, [_i, _i, _i, _i, _i, _i, _pp]),
     "cc_eval_destroy": (None, [_vp]),

@@ -217,8 +217,19 @@ struct SocketTransport : Transport {
         io_ok = recv_all(peers[(size_t)r], recv + (size_t)r * count, count * sizeof(int32_t));
       } else {  // drain what the peer sends, then tell everybody
         same = false;
-        sink.resize((size_t)m * sizeof(int32_t));
-        io_ok = recv_all(peers[(size_t)r], sink.data(), sink.size());
+        // in fixed pieces: the count comes from the peer, and a broken or hostile one must not size an allocation here
+        constexpr uint64_t kMaxDrainElems = 1ull << 28;  // 1 GiB of int32: far beyond any gather of detections
+        if (m > kMaxDrainElems) {
+          errno = EPROTO;
+          io_ok = false;
+          break;
+        }
+        sink.resize(1 << 16);
+        for (uint64_t left = m * sizeof(int32_t); left > 0 && io_ok;) {
+          const size_t piece = (size_t)std::min<uint64_t>(left, sink.size());
+          io_ok = recv_all(peers[(size_t)r], sink.data(), piece);
+          left -= piece;
+        }
       }
     }
     if (!io_ok) return set_error(CC_ERR_IO, "tcp transport: rank 0 lost a peer (%s)", std::strerror(errno));

@@ -810,7 +810,12 @@ struct Plan {
   long long windows = 0, integral_elems = 0;
   int n_resize_blocks = 0, n_bands = 0, n_col_blocks = 0, n_grid_rows = 0, n_diag_blocks = 0, n_tcol_blocks = 0;
   size_t h_frame_elems = 0;
-  int n_tiles = 0;
+  int n_tiles = 0;  // tiles of TILE_Y window rows (the ahead-of-time kernels); other heights: tiles_for
+  struct TileList {
+    int n = 0;
+    DevBuf<int4> d;
+  };
+  std::map<int, std::unique_ptr<TileList>> other_tiles;  // tile lists for other tile heights (run-time specialised kernels)
   DevBuf<ScaleDev> d_sd;
   DevBuf<int> d_resize_first, d_band_first, d_col_first, d_gridrow_first, d_diag_first, d_tcol_first, d_xofs, d_yofs;
   DevBuf<uint16_t> d_xw1, d_yw1;
@@ -856,6 +861,8 @@ struct BatchSink {
 
 using namespace ccamd;
 
+constexpr int kStageSlots = 3;  // staging slots for host frames (run_batch: why three)
+
 struct cc_detector {
   Cascade m;
   unsigned long long serial = 0;  // unique per created detector (tickets name their owner by it, not by address alone)
@@ -887,6 +894,7 @@ struct cc_detector {
   size_t lds_spec = 0;  // the same for the installed specialised kernel (smaller when its STEP-2 tiles hold 16-bit entries)
   size_t lds_extra = 0; // CCAMD_DEBUG_EXTRA_LDS (occupancy experiments)
   int spec_tmode = 0;  // TILE_32 / TILE_16 / TILE_PAIR16 of the installed specialised kernel
+  int spec_tile_y = TILE_Y;  // window rows per tile the installed specialised kernel was compiled for (spec_tile_rows)
   DevBuf<HaarStumpP16> d_haar_p16, d_haar_p16w;  // table-driven stumps of the pair tile: stage order, wave-phase order
   // plans + workspace
   std::vector<std::unique_ptr<Plan>> plans;
@@ -921,8 +929,9 @@ struct cc_detector {
   int* h_counts = nullptr;  // pinned, 2 x 2 ints
   uint8_t* h_frame = nullptr;  // pinned staging copy of a single host image (graph path)
   size_t h_frame_bytes = 0;
-  uint8_t* h_stage = nullptr;  // pinned staging area for batches of host frames, two slots like d_frames (stage_host_frames)
+  uint8_t* h_stage = nullptr;  // pinned staging area for batches of host frames, kStageSlots slots like d_frames (stage_host_frames)
   size_t h_stage_bytes = 0;
+  int stage_slot = 0;          // staging slot the next pass of host frames takes (round-robin, also across calls)
   int use_graph = 1;
   int early_skip = 1, full_sqsum = 0, pipeline_passes = 4, pipeline_passes_set = 0, even_passes = 0;  // tuning knobs, read once at creation
   hipStream_t copy_stream = nullptr;
@@ -2103,6 +2112,37 @@ static bool same_params(const cc_detect_params& a, const cc_detect_params& b) {
   return a.scale_factor == b.scale_factor && a.min_w == b.min_w && a.min_h == b.min_h && a.max_w == b.max_w && a.max_h == b.max_h;
 }
 
+// Tile list {scale, tx, ty, 0} of a plan for tiles of `tile_y` window rows.
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2): the list is permuted so that the tiles
+// one XCD receives are neighbours in the image and share their halo rows/columns in that XCD's L2. Placement only changes
+// speed, never results.
+static int debug_only_step() {  // timing experiments (CCAMD_DEBUG_ONLY_STEP=1|2): only the tiles of STEP-1 / STEP-2 scales are evaluated
+  static const int v = []() {
+    const char* e = std::getenv("CCAMD_DEBUG_ONLY_STEP");
+    return e ? std::atoi(e) : 0;
+  }();
+  return v;
+}
+static std::vector<int4> plan_tile_list(const std::vector<ScaleGeom>& geom, int tile_y) {
+  std::vector<int4> tiles;
+  for (size_t i = 0; i < geom.size(); i++) {
+    const ScaleGeom& g = geom[i];
+    if (debug_only_step() && g.ystep != debug_only_step()) continue;
+    const int ntx = (g.nx + TILE_X - 1) / TILE_X, nty = (g.ny + tile_y - 1) / tile_y;
+    for (int ty_ = 0; ty_ < nty; ty_++)
+      for (int tx_ = 0; tx_ < ntx; tx_++) tiles.push_back(make_int4((int)i, tx_, ty_, 0));
+  }
+  const size_t n = tiles.size(), per = (n + 7) / 8;
+  std::vector<int4> perm;
+  perm.reserve(n);
+  for (size_t j = 0; j < per; j++)
+    for (size_t x = 0; x < 8; x++) {
+      const size_t src = x * per + j;
+      if (src < n) perm.push_back(tiles[src]);
+    }
+  return perm;
+}
+
 static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params& p, Plan** out) {
   for (auto& pl : d->plans)
     if (pl->w == w && pl->h == h && same_params(pl->p, p)) {
@@ -2120,7 +2160,6 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
   long long h_ofs = 0;
   std::vector<int> xofs, yofs;
   std::vector<uint16_t> xw1, yw1;
-  std::vector<int4> tiles;
   long long img_ofs = 0, int_ofs = 0, mask_ofs = 0, win_ofs = 0;
   P->sd.resize(ns);
   for (int i = 0; i < ns; i++) {
@@ -2162,9 +2201,6 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
     gridrow_first[i + 1] = gridrow_first[i] + g.ny;
     diag_first[i + 1] = diag_first[i] + (g.w + g.h - 1 + 255) / 256;  // k_diag_sums: a thread walks 4 diagonals
     tcol_first[i + 1] = tcol_first[i] + (g.w + 1 + 63) / 64;
-    const int ntx = (g.nx + TILE_X - 1) / TILE_X, nty = (g.ny + TILE_Y - 1) / TILE_Y;
-    for (int ty_ = 0; ty_ < nty; ty_++)
-      for (int tx_ = 0; tx_ < ntx; tx_++) tiles.push_back(make_int4(i, tx_, ty_, 0));
   }
   P->pyr_frame_bytes = (size_t)((img_ofs + 15) & ~15LL);
   P->int_frame_elems = (size_t)int_ofs;
@@ -2177,20 +2213,7 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
   P->n_grid_rows = gridrow_first[ns];
   P->n_diag_blocks = diag_first[ns];
   P->n_tcol_blocks = tcol_first[ns];
-  // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2): permute the tile list so that the
-  // tiles one XCD receives are neighbours in the image and share their halo rows/columns in that XCD's L2.
-  // Placement only changes speed, never results.
-  {
-    const size_t n = tiles.size(), per = (n + 7) / 8;
-    std::vector<int4> perm;
-    perm.reserve(n);
-    for (size_t j = 0; j < per; j++)
-      for (size_t x = 0; x < 8; x++) {
-        const size_t src = x * per + j;
-        if (src < n) perm.push_back(tiles[src]);
-      }
-    tiles.swap(perm);
-  }
+  std::vector<int4> tiles = plan_tile_list(P->geom, TILE_Y);
   P->n_tiles = (int)tiles.size();
   hipStream_t st = d->stream;
   CC_HIP(P->d_sd.upload(P->sd, st));
@@ -2353,14 +2376,25 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.cand_count = d->d_counts[slot].p;
     A.cand_cap = d->cand_cap;
     A.stamps = nullptr;
+    // the tile list of the kernel that runs: the specialised kernel may have been compiled for another tile height
+    const bool run_spec = d->spec_fn && d->m.max_nodes_per_tree <= 1;
+    int n_tiles = P->n_tiles;
+    const int4* tiles_p = P->d_tiles.p;
+    if (run_spec && d->spec_tile_y != TILE_Y) {
+      const auto it = P->other_tiles.find(d->spec_tile_y);  // built by ensure_spec_tiles before the pass (never inside a graph capture)
+      if (it == P->other_tiles.end() || !it->second)
+        return set_error(CC_ERR_HIP, "internal: no tile list for tiles of %d window rows", d->spec_tile_y);
+      n_tiles = it->second->n;
+      tiles_p = it->second->d.p;
+    }
     if (std::getenv("CCAMD_DEBUG_STAMPS")) {  // timing experiments: per-block phase stamps of the cascade kernel
-      CC_HIP(d->d_stamps.ensure((size_t)P->n_tiles * (size_t)nf * STAMP_SLOTS));
-      CC_HIP(hipMemsetAsync(d->d_stamps.p, 0, (size_t)P->n_tiles * (size_t)nf * STAMP_SLOTS * sizeof(unsigned long long), st));
+      CC_HIP(d->d_stamps.ensure((size_t)n_tiles * (size_t)nf * STAMP_SLOTS));
+      CC_HIP(hipMemsetAsync(d->d_stamps.p, 0, (size_t)n_tiles * (size_t)nf * STAMP_SLOTS * sizeof(unsigned long long), st));
       A.stamps = d->d_stamps.p;
     }
     A.dbg_codes = debug ? d->d_dbg_codes.p : nullptr;
     A.dbg_sums = debug ? d->d_dbg_sums.p : nullptr;
-    A.tiles = P->d_tiles.p;
+    A.tiles = tiles_p;
     A.stumps1 = haar ? (const void*)d->d_haar1.p : (const void*)d->d_lbp1.p;
     A.stumps2 = haar ? (const void*)d->d_haar2.p : (const void*)d->d_lbp2.p;
     A.wstumps1 = d->d_haar1w.p ? (const void*)d->d_haar1w.p : A.stumps1;
@@ -2378,10 +2412,10 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.tree_root = d->d_tree_root.p;
     A.tree_leaf0 = d->d_tree_leaf0.p;
     A.leaves = d->d_leaves.p;
-    if (P->n_tiles) {
+    if (n_tiles) {
       if (d->spec_fn && !A.trees) {
         void* params[] = {&A};
-        CC_HIP(hipModuleLaunchKernel(d->spec_fn, (unsigned)P->n_tiles, (unsigned)nf, 1, EVAL_THREADS, 1, 1, (unsigned)d->lds_spec, st, params, nullptr));
+        CC_HIP(hipModuleLaunchKernel(d->spec_fn, (unsigned)n_tiles, (unsigned)nf, 1, EVAL_THREADS, 1, 1, (unsigned)d->lds_spec, st, params, nullptr));
       } else if (haar)
         hipLaunchKernelGGL(k_eval_haar, dim3(P->n_tiles, nf), dim3(EVAL_THREADS), d->lds, st, A);
       else
@@ -2403,10 +2437,11 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   CC_HIP(hipGetLastError());
   if (const char* path = std::getenv("CCAMD_DEBUG_STAMPS")) {  // dump [n_tiles * nf][STAMP_SLOTS] u64 (overwritten per pass)
     CC_HIP(hipStreamSynchronize(st));
-    std::vector<unsigned long long> h((size_t)P->n_tiles * (size_t)nf * STAMP_SLOTS);
+    const int n_tiles_run = (d->spec_fn && d->m.max_nodes_per_tree <= 1 && d->spec_tile_y != TILE_Y) ? P->other_tiles[d->spec_tile_y]->n : P->n_tiles;
+    std::vector<unsigned long long> h((size_t)n_tiles_run * (size_t)nf * STAMP_SLOTS);
     CC_HIP(hipMemcpy(h.data(), d->d_stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (FILE* f = std::fopen(path, "wb")) {
-      const int hdr[4] = {P->n_tiles, nf, STAMP_SLOTS, 0};
+      const int hdr[4] = {n_tiles_run, nf, STAMP_SLOTS, 0};
       std::fwrite(hdr, sizeof(int), 4, f);
       std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
       std::fclose(f);
@@ -2425,6 +2460,21 @@ static cc_status check_frame_args(const cc_detector* d, const uint8_t* frames, i
     return set_error(CC_ERR_INVALID_ARG, "%s: bad frame geometry (%dx%d, stride %zu, n %d)", who, width, height, row_stride, n_frames);
   if (width > 32768 || height > 32768) return set_error(CC_ERR_UNSUPPORTED, "%s: frames larger than 32768 px per side", who);
   if (!(p->scale_factor > 1.0)) return set_error(CC_ERR_INVALID_ARG, "%s: scaleFactor must be > 1", who);
+  return CC_OK;
+}
+
+// The specialised kernel may use another tile height than the ahead-of-time kernels: its tile list is built on first use,
+// with a synchronous copy -- so before the pass is launched, and never from inside a hipGraph capture.
+static cc_status ensure_spec_tiles(cc_detector* d, Plan* P) {
+  if (!d->spec_fn || d->m.max_nodes_per_tree > 1 || d->spec_tile_y == TILE_Y) return CC_OK;
+  std::unique_ptr<Plan::TileList>& tl = P->other_tiles[d->spec_tile_y];
+  if (tl) return CC_OK;
+  std::unique_ptr<Plan::TileList> fresh(new Plan::TileList);
+  const std::vector<int4> tv = plan_tile_list(P->geom, d->spec_tile_y);
+  fresh->n = (int)tv.size();
+  CC_HIP(fresh->d.ensure(std::max<size_t>(tv.size(), 1)));
+  if (!tv.empty()) CC_HIP(hipMemcpy(fresh->d.p, tv.data(), tv.size() * sizeof(int4), hipMemcpyHostToDevice));
+  tl = std::move(fresh);
   return CC_OK;
 }
 
@@ -2513,7 +2563,7 @@ static cc_status stage_host_frames(cc_detector* d, const uint8_t* src, int nf, i
                               hipMemcpyHostToDevice, front));
     return CC_OK;
   }
-  const size_t need = fs * (size_t)d->pass_capacity * 2;
+  const size_t need = fs * (size_t)d->pass_capacity * kStageSlots;
   if (d->h_stage_bytes < need) {
     if (d->h_stage) {
       CC_HIP(hipStreamSynchronize(front));  // no copy may still be reading the old area
@@ -2594,6 +2644,8 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
   spec_poll(d);
   Plan* P = nullptr;
   stt = build_plan(d, width, height, *p, &P);
+  if (stt != CC_OK) return stt;
+  stt = ensure_spec_tiles(d, P);
   if (stt != CC_OK) return stt;
   if (!d->copy_stream) {
     CC_HIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
@@ -2750,6 +2802,35 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     sizes.swap(fixed);
   }
   for (int v : sizes) d->pass_capacity = std::max(d->pass_capacity, v);  // the workspace only ever grows
+  // Host frames: THREE staging slots (device and pinned), handed out round-robin across passes and calls. The frames of
+  // pass i + 1 are staged and their copy issued right after pass i is launched and BEFORE the pass before it is fetched
+  // (a blocking wait), so the host copy and the H2D transfer of a pass run a whole pass ahead of the kernels that read
+  // them. Two slots are not enough for that: the slot of pass i + 1 would be the one of pass i - 1, which is still
+  // unfetched at that point and re-reads its frames if it has to be redone (candidate-list overflow). With three, the slot
+  // that is overwritten belongs to pass i - 2, fetched when pass i - 1 was launched.
+  const uint8_t* prestaged = nullptr;
+  auto stage_pass = [&](int pf0, int pnf, const uint8_t** where) -> cc_status {
+    const size_t rs = (size_t)align_up(width, 4), fs = rs * (size_t)height;
+    const size_t need = fs * (size_t)d->pass_capacity * kStageSlots;
+    if (d->d_frames.n < need && d->pending.active) {
+      // Growing the staging area frees it, and the unfetched pass still names its frames there (round-3 advisor finding).
+      if (d->pending.sink == sink) {
+        const cc_status st2 = retire_pending(d);
+        if (st2 != CC_OK) return st2;
+      } else
+        retire_foreign(d);
+    }
+    if (d->d_frames.n < need) d->stage_slot = 0;
+    CC_HIP(d->d_frames.ensure(need));
+    const int sslot = d->stage_slot;
+    d->stage_slot = (d->stage_slot + 1) % kStageSlots;
+    uint8_t* stage = d->d_frames.p + (size_t)sslot * fs * (size_t)d->pass_capacity;
+    const cc_status st2 = stage_host_frames(d, frames + (size_t)pf0 * frame_stride, pnf, width, height, row_stride, frame_stride, stage, rs, fs,
+                                            sslot, front);
+    if (st2 != CC_OK) return st2;
+    *where = stage;
+    return CC_OK;
+  };
   // spec_poll may have installed another kernel: a pending pass keeps the results it was launched for, nothing to redo.
   int f0 = 0;
   for (size_t pi = 0; pi < sizes.size(); f0 += sizes[pi], pi++) {
@@ -2765,25 +2846,15 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     ps.sink = sink;
     if (on_device) {
       ps.dptr = frames + (size_t)f0 * frame_stride;
-    } else {  // staging area is double-buffered like the results
+    } else {
       ps.rs = (size_t)align_up(width, 4);
       ps.fs = ps.rs * (size_t)height;
-      const size_t need = ps.fs * (size_t)d->pass_capacity * 2;
-      if (d->d_frames.n < need && d->pending.active) {
-        // Growing the staging area frees it, and the unfetched pass still names its frames there (it would re-read them if
-        // it had to be redone: candidate-list overflow). Fetch it first (round-3 advisor finding).
-        if (d->pending.sink == sink) {
-          stt = retire_pending(d);
-          if (stt != CC_OK) return stt;
-        } else
-          retire_foreign(d);
+      if (!prestaged) {
+        stt = stage_pass(f0, sizes[pi], &prestaged);
+        if (stt != CC_OK) return stt;
       }
-      CC_HIP(d->d_frames.ensure(need));
-      uint8_t* stage = d->d_frames.p + (size_t)slot * ps.fs * (size_t)d->pass_capacity;
-      stt = stage_host_frames(d, frames + (size_t)f0 * frame_stride, ps.nf, width, height, row_stride, frame_stride, stage, ps.rs,
-                              ps.fs, slot, front);
-      if (stt != CC_OK) return stt;
-      ps.dptr = stage;
+      ps.dptr = prestaged;
+      prestaged = nullptr;
     }
     // the slot's result buffers are free: the pass that used them last was retired when the pass after it was launched
     static const bool trace_host = std::getenv("CCAMD_TRACE_HOST") != nullptr;  // host-side timeline of the pass loop (stderr)
@@ -2797,6 +2868,11 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     th("launched");
     ps.cap = d->cand_cap;
     ps.gen = d->list_gen;
+    if (!on_device && pi + 1 < sizes.size() && want_results) {  // the next pass's frames travel while this pass runs
+      stt = stage_pass(f0 + sizes[pi], sizes[pi + 1], &prestaged);
+      if (stt != CC_OK) return stt;
+      th("next pass staged");
+    }
     if (want_results) {
       CC_HIP(hipMemcpyAsync(d->h_counts + 2 * slot, d->d_counts[slot].p, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
       CC_HIP(hipEventRecord(d->pass_done[slot], d->stream));
@@ -2912,12 +2988,25 @@ static const char kSpecPrelude[] =
     "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
 
 // Compiles `src` for `arch`; identical (source, options) pairs are served from a per-process cache.
-static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, bool lbp, int tmode, int win_w, int win_h, std::vector<char>& code) {
+// Window rows per tile of a run-time specialised kernel (its -DCC_TILE_Y). LBP kernels whose STEP-2 tiles hold 16-bit entries
+// take 16 rows (64 x 16 windows per block of 256 threads): a tile's halo rows are staged per 16 instead of per 8 window
+// rows, the per-block work (barrier rounds, counters, the wave phase's window collection) is paid once per 1024 windows, and
+// the late stages find twice the windows per block to fill their wavefronts with; at 22.7 KB per block seven blocks still fit
+// a CU. Measured on the stock LBP cascade, ms per 32 Full-HD frames alone: 8 rows 4.84, 12 rows 4.47, 16 rows 4.38
+// (tools/r4_e.sh). Haar kernels stay at the library's 8 (31 KB tiles: 16 rows leave 3 blocks per CU, 9.5 against 7.9 ms).
+static int spec_tile_rows(const Cascade& m, int tmode) {
+  int ty = (m.feature_type == CC_FEATURE_LBP && tmode == TILE_16) ? 16 : TILE_Y;
+  if (const char* e = std::getenv("CCAMD_SPEC_TILE_Y")) ty = std::atoi(e);  // tuning
+  if (ty < EVAL_WAVES || ty > 32 || ty % EVAL_WAVES != 0 || tmode == TILE_PAIR16) ty = TILE_Y;
+  return ty;
+}
+
+static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, bool lbp, int tmode, int tile_y, int win_w, int win_h, std::vector<char>& code) {
   const bool tile16 = tmode == TILE_16;
   static std::mutex mu;
   static std::map<std::string, std::vector<char>> cache;
   const std::string o_arch = "--offload-arch=" + arch, o_k = "-DCC_SPEC_STAGES=" + std::to_string(n_stages);
-  const std::string o_ty = "-DCC_TILE_Y=" + std::to_string(TILE_Y), o_th = "-DCC_EVAL_THREADS=" + std::to_string(EVAL_THREADS);
+  const std::string o_ty = "-DCC_TILE_Y=" + std::to_string(tile_y), o_th = "-DCC_EVAL_THREADS=" + std::to_string(EVAL_THREADS);
   // same code generation rules as the ahead-of-time build (Makefile): no FMA contraction, no fast-math
   // register budget = the occupancy the LDS footprint allows: 5 blocks per CU with the 32-bit tile, 7-8 with the 16-bit one
   std::string o_w = "-DCC_EVAL_MIN_WAVES_PER_EU=" + std::to_string(tile16 ? 7 : CC_EVAL_MIN_WAVES_PER_EU);
@@ -3076,11 +3165,12 @@ static cc_status spec_build(const Cascade& m, int n_stages, const std::string& a
   src.replace(pos, marker.size(), spec_stage_source(m, k, tmode));
   k_out = k;
   tmode_out = tmode;
-  return compile_specialised(src, arch, k, m.feature_type == CC_FEATURE_LBP, tmode, m.win_w, m.win_h, code);
+  return compile_specialised(src, arch, k, m.feature_type == CC_FEATURE_LBP, tmode, spec_tile_rows(m, tmode), m.win_w, m.win_h, code);
 }
 
 // Device half: load the code object and make it the detector's cascade kernel. Owning thread only.
 static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int k, int tmode) {
+  retire_foreign(d);  // a pass still unfetched was launched with the old kernel (and its tile list): fetch it before the switch
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   CC_HIP(hipModuleLoadData(&mod, code.data()));
@@ -3088,11 +3178,18 @@ static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int
     (void)hipModuleUnload(mod);
     return set_error(CC_ERR_HIP, "cc_detector_specialize: entry point not found in the compiled module");
   }
+  const int ty = spec_tile_rows(d->m, tmode);
+  const bool haar_k = d->m.feature_type == CC_FEATURE_HAAR;
   size_t lds_spec = d->lds;
-  if (tmode == TILE_16) {  // STEP-1 tile in 32 bits, STEP-2 tile in 16 bits
-    const TileGeom<1> G1(d->m.win_w, d->m.win_h);
-    const TileGeom16 G2(d->m.win_w, d->m.win_h);
-    lds_spec = eval_lds_bytes(std::max(G1.words(), G2.words()), false) + d->lds_extra;
+  if (tmode == TILE_32) {
+    const TileGeom<1> G1(d->m.win_w, d->m.win_h, ty);
+    const TileGeom<2> G2(d->m.win_w, d->m.win_h, ty);
+    const int words = debug_only_step() == 1 ? G1.words() : debug_only_step() == 2 ? G2.words() : std::max(G1.words(), G2.words());
+    lds_spec = eval_lds_bytes(words, d->m.has_tilted, haar_k, ty) + d->lds_extra;
+  } else if (tmode == TILE_16) {  // STEP-1 tile in 32 bits, STEP-2 tile in 16 bits
+    const TileGeom<1> G1(d->m.win_w, d->m.win_h, ty);
+    const TileGeom16 G2(d->m.win_w, d->m.win_h, ty);
+    lds_spec = eval_lds_bytes(std::max(G1.words(), G2.words()), false, haar_k, ty) + d->lds_extra;
   } else if (tmode == TILE_PAIR16) {  // STEP-2 tile of window pairs, with partial sums for both windows of a slot
     const TileGeom<1> G1(d->m.win_w, d->m.win_h);
     const TileGeomP G2(d->m.win_w, d->m.win_h);
@@ -3133,6 +3230,7 @@ static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int
   d->spec_stages = k;
   d->lds_spec = lds_spec;
   d->spec_tmode = tmode;
+  d->spec_tile_y = ty;
   return CC_OK;
 }
 
@@ -3183,6 +3281,41 @@ static cc_status spec_start_background(cc_detector* d, int n_stages) {
 
 }  // namespace ccamd
 
+// Parity instrumentation of inv_sqrt_as_float (cc_eval_kernel.inc): counts values nf for which it differs from
+// (float)(1.0 / sqrt(nf)). nf is drawn as the kernels form it -- area * valsqsum - valsum^2 for a random window size, pixel
+// sum and squared sum (an integer-valued double) -- and, every fourth draw, as an arbitrary integer below 2^52.
+namespace ccamd {
+__global__ void k_vnf_check(unsigned long long seed, int per_thread, unsigned long long* mismatches) {
+  unsigned long long x = seed + (unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+  auto next = [&]() {
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    return x;
+  };
+  unsigned long long bad = 0;
+  for (int i = 0; i < per_thread; i++) {
+    const unsigned long long r = next();
+    double nf;
+    if ((i & 3) == 3) {
+      nf = (double)(1ull + (next() >> 12));
+    } else {
+      const unsigned w = 1u + (unsigned)(r & 0xffu), h = 1u + (unsigned)((r >> 8) & 0xffu);
+      const double area = (double)(w * h);
+      const unsigned long long n = (unsigned long long)w * h;
+      const unsigned long long sm = (r >> 16) % (255ull * n + 1ull);
+      // any squared sum a window with that pixel sum can have: between sm^2 / n and 255 * sm
+      const unsigned long long lo_sq = (sm * sm + n - 1) / n, hi_sq = 255ull * sm;
+      const unsigned long long sq = lo_sq + (hi_sq > lo_sq ? next() % (hi_sq - lo_sq + 1ull) : 0ull);
+      nf = area * (double)(unsigned)sq - (double)(int)sm * (double)(int)sm;  // the kernels' expression (valsqsum wraps at 2^32 like theirs)
+    }
+    if (!(nf > 0.)) continue;
+    if (__float_as_uint(inv_sqrt_as_float(nf)) != __float_as_uint((float)(1. / sqrt(nf)))) bad++;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+}  // namespace ccamd
+
 extern "C" {
 
 int cc_device_count(void) {
@@ -3225,7 +3358,7 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
   d->stream = d->own_stream;
   const TileGeom<1> G1(d->m.win_w, d->m.win_h);
   const TileGeom<2> G2(d->m.win_w, d->m.win_h);
-  d->lds = eval_lds_bytes(std::max(G1.words(), G2.words()), d->m.has_tilted);
+  d->lds = eval_lds_bytes(std::max(G1.words(), G2.words()), d->m.has_tilted, d->m.feature_type == CC_FEATURE_HAAR);
   if ((int)d->m.stage_ntrees.size() >= MAX_STAGES)
     return set_error(CC_ERR_UNSUPPORTED, "cc_detector_create: cascades with %zu stages are not supported (limit %d)",
                      d->m.stage_ntrees.size(), MAX_STAGES - 1);
@@ -3732,6 +3865,24 @@ cc_status cc_detect_debug_windows(cc_detector* d, const uint8_t* gray, int width
 }
 
 // ---- building blocks -------------------------------------------------------------------------------------------
+cc_status cc_debug_vnf_check(int device, uint64_t n_values, uint64_t seed, uint64_t* mismatches) {
+  if (!mismatches) return set_error(CC_ERR_INVALID_ARG, "cc_debug_vnf_check: null output");
+  cc_status st = ensure_device(device);
+  if (st != CC_OK) return st;
+  unsigned long long* d = nullptr;
+  CC_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned long long)));
+  CC_HIP(hipMemset(d, 0, sizeof(unsigned long long)));
+  const int threads = 256, blocks = 4096;
+  const int per_thread = (int)std::max<uint64_t>(1, std::min<uint64_t>((n_values + (uint64_t)threads * blocks - 1) / ((uint64_t)threads * blocks), 1u << 20));
+  hipLaunchKernelGGL(k_vnf_check, dim3(blocks), dim3(threads), 0, 0, (unsigned long long)seed, per_thread, d);
+  unsigned long long h = 0;
+  const hipError_t e2 = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e2 != hipSuccess) return set_error(CC_ERR_HIP, "cc_debug_vnf_check: %s", hipGetErrorString(e2));
+  *mismatches = h;
+  return CC_OK;
+}
+
 cc_status cc_resize_linear_exact_u8(int device, const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, int dw, int dh,
                                     size_t dstride) {
   if (!src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1 || sstride < (size_t)sw || dstride < (size_t)dw)

@@ -306,6 +306,13 @@ __global__ __launch_bounds__(BATCH_THREADS) void k_eval_batch_wide(BatchArgs A) 
         if (valid) out[(size_t)(f - A.feat_begin) * A.out_pitch] = F.w[0];
         return;
       }
+      if (A.debug_nostore == 3) {  // timing experiment: the store stream alone in 512-byte pieces (every second tile writes two)
+        if (!(tile & 1)) {
+          if (valid) out[(size_t)(f - A.feat_begin) * A.out_pitch] = F.w[0];
+          if (s0 + 64 + s < A.n_samples) out[(size_t)(f - A.feat_begin) * A.out_pitch + 64] = F.w[0];
+        }
+        return;
+      }
       float ret = F.w[0] * (float)(at(F.p[0][0]) - at(F.p[0][1]) - at(F.p[0][2]) + at(F.p[0][3])) +
                   F.w[1] * (float)(at(F.p[1][0]) - at(F.p[1][1]) - at(F.p[1][2]) + at(F.p[1][3]));
       if (F.w[2] != 0.0f) ret += F.w[2] * (float)(at(F.p[2][0]) - at(F.p[2][1]) - at(F.p[2][2]) + at(F.p[2][3]));
@@ -999,9 +1006,14 @@ cc_status cc_eval_calc_batch_sorted(cc_evaluator* e, int fi_begin, int fi_end, i
   CC_HIP(offsets.ensure((size_t)nf + 1));
   st = launch_batch(e, haar, haar ? (const void*)e->d_haar.p : (const void*)e->d_lbp.p, fi_begin, fi_end, nullptr, n_samples, e->d_out.p, 1, 0);
   if (st != CC_OK) return st;
+  bool sorted_in_blocks = false;
   if (n_samples <= sort_rows_block_limit()) {  // one block per row, the row in registers + LDS (cc_split.hip)
-    CC_HIP(sort_rows_block(e->d_out.p, nf, n_samples, keys_out.p, sorted.p, e->stream));
-  } else {
+    if (sort_rows_block(e->d_out.p, nf, n_samples, keys_out.p, sorted.p, e->stream) == hipSuccess)
+      sorted_in_blocks = true;
+    else
+      (void)hipGetLastError();  // refused LDS request / launch: the device-wide segmented sort below
+  }
+  if (!sorted_in_blocks) {
     std::vector<int> off((size_t)nf + 1);
     for (int i = 0; i <= nf; i++) off[(size_t)i] = i * n_samples;
     CC_HIP(hipMemcpyAsync(offsets.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, e->stream));

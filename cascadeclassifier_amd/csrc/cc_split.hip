@@ -89,7 +89,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_rows_block(const float* _
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {  // blocked arrangement: thread t owns positions t * ITEMS ..
     const int pos = (int)threadIdx.x * ITEMS + i;
-    key[i] = pos < n ? src[pos] : __int_as_float(0x7f800000);  // padding sorts behind every finite value
+    // padding = +inf: sorts behind every finite value. Precondition: no NaN among the values (a NaN's radix key sorts behind
+    // +inf and would push padding into the first n ranks). The evaluators cannot produce one: Haar values are finite sums
+    // divided by a positive norm factor or 0 when it is 0 (haarfeatures.h:108-112), LBP codes are 0..255.
+    key[i] = pos < n ? src[pos] : __int_as_float(0x7f800000);
     val[i] = (unsigned short)pos;
   }
   Sort(temp).SortBlockedToStriped(key, val);
@@ -104,12 +107,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_rows_block(const float* _
 }
 template <int ITEMS>
 static hipError_t launch_sort_rows_block(const float* vals, int rows, int n, float* keys_out, int* idx_out, hipStream_t st) {
-  static bool attr_set = false;
   constexpr size_t lds = RowSort<ITEMS>::lds_bytes;
-  if (!attr_set && lds > 64 * 1024) {
+  if (lds > 64 * 1024) {
+    // The opt-in is per device and cheap: set it on every launch (a process-wide "done" flag, as round 3 kept, leaves the
+    // second device of a process without it, and is not thread-safe).
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_block<ITEMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((k_sort_rows_block<ITEMS>), dim3((unsigned)rows), dim3(SORT_THREADS), lds, st, vals, rows, n, keys_out, idx_out);
   return hipGetLastError();
@@ -595,9 +598,15 @@ cc_status cc_eval_presort_range(cc_evaluator* e, int fi_begin, int fi_end, int n
     const size_t total = (size_t)nf * N;
     st = launch_batch(e, true, feats, fi_begin + f0, fi_begin + f1, nullptr, N, e->d_out.p, 1, 0);
     if (st != CC_OK) return st;
+    bool sorted_in_blocks = false;
     if (N <= sort_rows_block_limit()) {  // a row fits one block: sorted in LDS, read once and written once
-      CC_HIP(sort_rows_block(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream));
-    } else {
+      // a part that refuses the ~100 KB LDS request (or the launch) takes the device-wide sort below instead of failing
+      if (sort_rows_block(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream) == hipSuccess)
+        sorted_in_blocks = true;
+      else
+        (void)hipGetLastError();
+    }
+    if (!sorted_in_blocks) {
       size_t temp_bytes = 0;
       CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
                                                          offsets.p, offsets.p + 1, 0, 32, e->stream));
@@ -720,7 +729,10 @@ cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, in
     A.dbg_nogather = std::getenv("CCAMD_DEBUG_SPLIT_NOGATHER") ? 1 : 0;
     // wavefronts per block: with the table in LDS one block owns a CU, so spread the groups evenly over the CUs
     // (162 336 variables = 2 537 groups -> 254 blocks of 10 wavefronts on 256 CUs); from global memory, one wavefront
-    static const bool lean = std::getenv("CCAMD_SPLIT_BRANCHY") == nullptr;  // A/B: the round-1 kernel for the 8-byte LDS table
+    // k_split_ord_lean for the regression / GINI searches (Gentle 6.77 against 7.01 ms, GINI 8.91 against 9.31 at configs[4]);
+    // the MISCLASS search has no division and nothing to hoist: the round-1 kernel stays (4.46 against 4.76 ms).
+    // CCAMD_SPLIT_BRANCHY=1: the round-1 kernel everywhere (A/B runs).
+    static const bool lean = std::getenv("CCAMD_SPLIT_BRANCHY") == nullptr;
     int wpb = 1;
     if (tab_kind != 0) {
       hipDeviceProp_t prop;
@@ -728,7 +740,7 @@ cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, in
       const int cus = std::max(1, prop.multiProcessorCount);
       wpb = (int)std::min<size_t>(16, std::max<size_t>(1, (groups + cus - 1) / cus));
       if (const char* v = std::getenv("CCAMD_SPLIT_WAVES")) wpb = std::max(1, std::min(16, std::atoi(v)));
-      if (tab_kind == 2 && lean) wpb = std::min(wpb, SPLIT_LEAN_WAVES);
+      if (tab_kind == 2 && lean && mode != 2) wpb = std::min(wpb, SPLIT_LEAN_WAVES);
     }
     const unsigned blocks = (unsigned)((groups + wpb - 1) / wpb);
     const size_t lds = tab_kind == 0 ? 0 : (size_t)N * entry_bytes;
@@ -751,7 +763,7 @@ cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, in
       CC_LAUNCH_ORD3(M, TI, 0);        \
     else if (tab_kind == 1)            \
       CC_LAUNCH_ORD3(M, TI, 1);        \
-    else if (lean)                     \
+    else if (lean && M != 2)           \
       CC_LAUNCH_LEAN(M, TI);           \
     else                               \
       CC_LAUNCH_ORD3(M, TI, 2);        \

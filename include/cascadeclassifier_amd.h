@@ -262,6 +262,10 @@ CC_API cc_status cc_debug_stream_dwords(int device, size_t n_bytes, int repeats,
  * on the device for n_pairs pseudo-random operand pairs of the evaluator's value ranges (x2: arbitrary floats and
  * integer-valued dividends over sqrt-shaped divisors); *mismatches must come back 0. */
 CC_API cc_status cc_debug_division_check(int device, uint64_t n_pairs, uint64_t seed, uint64_t* mismatches);
+/* Same kind of check for the cascade kernel's variance normalisation: counts values nf = area * valsqsum - valsum^2 (drawn
+ * as the kernels form them) for which the refined-rsqrt path differs from (float)(1.0 / sqrt(nf)), the CPU's two correctly
+ * rounded operations (cv::CascadeClassifier setWindow). Must report 0. */
+CC_API cc_status cc_debug_vnf_check(int device, uint64_t n_values, uint64_t seed, uint64_t* mismatches);
 /* Host-side (tiny, serial in the reference too): cv::groupRectangles(rects, group_threshold, eps). */
 CC_API cc_status cc_group_rectangles(const cc_rect* rects, int n, int group_threshold, double eps, cc_rect* out, int cap,
                                      int* n_out);

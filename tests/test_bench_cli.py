@@ -26,6 +26,46 @@ def test_multi_rank_launch_without_gpu_fails_loudly_and_does_not_hang():
     assert not r.stdout.strip().startswith("{")  # no headline number without a device
 
 
+@pytest.mark.parametrize("transport", ["tcp", "torch"])
+def test_configs3_gather_leg_rehearsed_with_eight_ranks_on_cpu(transport, monkeypatch):
+    """BASELINE configs[3] (512 frames over 8 ranks) has no 8-GPU node to run on here: `bench.py --gpus 8 --backend gloo
+    --rehearse-gather` runs what does not need one -- the script's own rank spawning, rendezvous on 127.0.0.1, the C ABI
+    communicator (loopback TCP transport) with its trial gather, or the torch collective, the per-step gathers of 8 x 64
+    frames (one rank without a rectangle) between the real run's barriers, the max-over-ranks reduction, one line from rank 0
+    -- and every child must exit 0."""
+    if transport == "tcp":
+        monkeypatch.setenv("CCAMD_COMM_TRANSPORT", "tcp")
+    else:
+        monkeypatch.delenv("CCAMD_COMM_TRANSPORT", raising=False)
+    r = _run(["--gpus", "8", "--backend", "gloo", "--rehearse-gather", "--frames", "64", "--steps", "3", "--warmup", "1"], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    codes = [ln for ln in r.stderr.splitlines() if ln.startswith("[bench] rank exit codes:")]
+    assert len(codes) == 1 and json.loads(codes[0].split(":", 1)[1]) == [0] * 8, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert "value" not in out and "metric" not in out  # a rehearsal is not a measurement
+    assert out["n_gpus"] == 8 and out["frames_per_step"] == 512 and out["every_rank_holds_all_frames_in_order"] is True
+    assert out["gather"].startswith("cc_gather_detections (C ABI, loopback TCP" if transport == "tcp" else "torch.distributed all_gather (gloo)")
+
+
+def test_eight_ranks_without_gpus_fail_loudly_with_their_exit_codes(monkeypatch):
+    """The real `--gpus 8` command on a box without GPUs: no line, a non-zero status, and the children's exit codes on
+    stderr (the first rank to die fails the job, the others are terminated: nobody waits in a rendezvous)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    monkeypatch.setenv("CCAMD_COMM_TRANSPORT", "tcp")
+    r = _run(["--gpus", "8", "--backend", "gloo", "--frames", "1", "--steps", "1", "--warmup", "0", "--width", "320", "--height", "240",
+              "--cpu-frames", "0"], timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    codes = [ln for ln in r.stderr.splitlines() if ln.startswith("[bench] rank exit codes:")]
+    assert len(codes) == 1
+    rc = json.loads(codes[0].split(":", 1)[1])
+    assert len(rc) == 8 and all(c != 0 for c in rc), rc
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_on_one_gpu_gloo():
     """The N > 1 leg end to end on the one-GPU box: two ranks share the card, detections are gathered over gloo

@@ -257,7 +257,7 @@ def _tcp_rank(rank, world, n_frames, case, id_q, out_q):
     assert (L.lib().cc_comm_rank(comm._c), L.lib().cc_comm_world(comm._c)) == (rank, world)
     lo, hi = shard_range(n_frames, rank, world)
     mine = [_fake_detections(f) for f in range(lo, hi)]
-    if case == "empty_rank" and rank == 1:
+    if (case == "empty_rank" and rank == 1) or (case == "configs3" and rank == 5):
         mine = [np.zeros((0, 4), np.int32) for _ in mine]  # frames, but not one rectangle
     res = {}
     if case == "bad_args" and rank == world - 1:
@@ -275,7 +275,7 @@ def _tcp_rank(rank, world, n_frames, case, id_q, out_q):
         except L.CascadeError as e:
             res["status"] = e.status
             res["msg"] = str(e)
-    elif case == "small_on_one" and rank == 0:
+    elif case in ("small_on_one", "configs3") and rank == 0:
         # rank 0 alone passes buffers that are too small: BUFFER_TOO_SMALL after the collectives, then cc_gather_fetch
         counts = np.array([len(r) for r in mine], np.int32)
         off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
@@ -342,6 +342,18 @@ def test_c_abi_gather_buffer_too_small_on_one_rank_only():
     got = _run_tcp_job(3, 7, "small_on_one")
     want = [_fake_detections(f).tolist() for f in range(7)]
     assert all(got[r]["all"] == want for r in range(3))
+
+
+def test_c_abi_gather_at_the_shape_of_baseline_configs3():
+    """BASELINE configs[3] as the 8-GPU run will see it, rehearsed on CPU over the tcp transport: world 8, 512 frames =
+    64 per rank, one rank whose frames hold no rectangle, rank 0 with too little room (CC_ERR_BUFFER_TOO_SMALL after the
+    collectives, then cc_gather_fetch). Every rank ends up with all 512 frames' rectangles in frame order and exits 0.
+    (ncclCommInitRank / ncclAllGather themselves with world > 1 stay unverified until a multi-GPU node runs them.)"""
+    got = _run_tcp_job(8, 512, "configs3")
+    lo, hi = shard_range(512, 5, 8)
+    assert (lo, hi) == (320, 384)
+    want = [([] if lo <= f < hi else _fake_detections(f).tolist()) for f in range(512)]
+    assert all(got[r]["all"] == want for r in range(8))
 
 
 def test_c_abi_gather_bad_arguments_on_one_rank_fail_everywhere_without_a_hang():

@@ -350,3 +350,16 @@ def test_background_specialisation_switches_over(haar_xml, monkeypatch):
     r = cc.CascadeClassifier(haar_xml)
     r.specialize_async(3)
     del r  # ... also while the build is still running
+
+
+def test_fast_variance_norm_factor_is_the_two_rounded_operations():
+    """Round 4: the cascade kernels take varianceNormFactor = (float)(1.0 / sqrt(nf)) from v_rsq_f64 + two Newton steps,
+    with the two correctly rounded operations as the fallback near a float rounding boundary. Over 2^32 values of nf drawn
+    as the kernels form them (area * valsqsum - valsum^2, every window size up to 256 x 256) plus arbitrary integers below
+    2^52: no value may differ."""
+    import ctypes as C
+    bad = C.c_uint64(123)
+    L.check(L.lib().cc_debug_vnf_check(0, 1 << 32, 20261005, C.byref(bad)))
+    assert bad.value == 0
+    L.check(L.lib().cc_debug_vnf_check(0, 1 << 28, 7, C.byref(bad)))
+    assert bad.value == 0
