@@ -85,6 +85,40 @@ def corner_reads_frame0(clf, frame, scale_factor):
     return int(reads[vis != 0].sum())
 
 
+PROFILE_ROUND = "r04"  # profiles/<round>_traffic_k_eval*.json, profiles/<round>_pmc_eval*.json
+
+
+def replay_counters(suffix, kernel_name, cascade_file, frames_per_launch, full_hd):
+    """Counter-based figures (HBM traffic, LDS / VALU busy, wait shares) need their own rocprofv3 passes (tools/profile_bench.sh,
+    tools/pmc_eval.sh): a bench run can only REPLAY the committed measurement, and does so only when that profile was taken
+    from the very kernel sources this run executes (sha of the kernel files recorded next to the numbers), for the same
+    kernel and cascade. Returns (traffic bytes per launch or None, note, secondary dict or None)."""
+    src_sha = kernel_source_sha16()
+    traffic, note, secondary = None, None, None
+    tname = f"profiles/{PROFILE_ROUND}_traffic_k_eval{suffix}.json"
+    tfile = os.path.join(ROOT, tname)
+    if os.path.exists(tfile) and full_hd:
+        tj = json.load(open(tfile))
+        if tj.get("kernel_src_sha16") == src_sha and tj.get("kernel") == kernel_name and tj.get("cascade", cascade_file) == cascade_file:
+            traffic = round(tj["hbm_bytes_per_frame"] * frames_per_launch)
+            note = {"replayed_from": tname, "profile_kernel_src_sha16": src_sha,
+                    "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes, FETCH x2 (gfx950), scaled to this run's frames per launch"}
+        else:
+            note = {"refused": f"{tname} was measured on other kernel sources, another kernel or another cascade "
+                               f"({tj.get('kernel')}, {tj.get('cascade')}, {tj.get('kernel_src_sha16')} vs {kernel_name}, {cascade_file}, {src_sha}): "
+                               "re-run tools/profile_bench.sh"}
+    pname = f"profiles/{PROFILE_ROUND}_pmc_eval{suffix}.json"
+    pfile = os.path.join(ROOT, pname)
+    if os.path.exists(pfile) and full_hd:
+        pj = json.load(open(pfile))
+        if pj.get("kernel_src_sha16") == src_sha and pj.get("kernel") == kernel_name and pj.get("cascade", cascade_file) == cascade_file:
+            secondary = {k: pj.get(k) for k in ("lds_pipeline_busy", "lds_bank_conflict_share", "valu_busy", "valu_active_counter_share",
+                                                "wave_cycles_waiting_on_counter_or_barrier", "wave_cycles_ready_not_issued", "wave_cycles_issuing")}
+            secondary["replayed_from"] = pname + " (tools/pmc_eval.sh)"
+            secondary["profile_kernel_src_sha16"] = src_sha
+    return traffic, note, secondary
+
+
 def measure_extra_workload(cc, torch, dev, dev_index, cascade, specialize, frames_host, args, label):
     """One of the post-headline workloads (rank 0, N = 1; outside the headline's timed region): the same step as the
     headline -- resident frames, whole detection path incl. copy-back + grouping -- for another cascade / frame content.
@@ -135,11 +169,15 @@ def measure_extra_workload(cc, torch, dev, dev_index, cascade, specialize, frame
     from oracle import oracle as orc
     want = orc.detect_multiscale(orc.load_cascade_xml(cascade), frames_host[0], args.scale_factor, args.min_neighbors, nthreads=usable_cores())
     same = want.shape == last[0].shape and bool((want == last[0]).all())
+    kernel_name = "k_eval_spec" if spec else ("k_eval_haar" if inf["feature_type"] == 0 else "k_eval_lbp")
+    full_hd = (W, H) == (1920, 1080) and abs(args.scale_factor - 1.1) < 1e-12 and args.content == "natural" and "uniform" not in label
+    traffic, traffic_note, secondary = replay_counters("" if inf["feature_type"] == 0 else "_lbp", kernel_name, os.path.basename(cascade), fpl, full_hd)
     del clf
     return {"workload": label, "value": round(wpf * B * steps / dt / 1e6, 3), "unit": "Mwindows/s", "ms_per_step": round(dt / steps * 1e3, 4),
             "steps": steps, "frames_per_step": B, "kernel_specialized_stages": spec, "cascade_kernel_ms_per_launch": round(eval_ms, 4),
             "frames_per_launch": fpl, "roofline_frac_hbm": round(ach / HBM_PEAK_GBS, 5), "achieved_GBps": round(ach, 2),
-            "lds_frac": round(lds_ach / (256 * 128 * 2.4), 4), "rectangles_identical_to_cpu_oracle_frame0": same}
+            "lds_frac": round(lds_ach / (256 * 128 * 2.4), 4), "traffic": traffic, "traffic_source": traffic_note, "secondary": secondary,
+            "rectangles_identical_to_cpu_oracle_frame0": same}
 
 
 def measure_training_eval(cc, torch):
@@ -494,9 +532,10 @@ def main():
                 prev = t
             return clf.detect_batch_collect(prev)
         host_last = host_steps(2)
+        kh = max(k, args.steps)  # as many steps as the headline: the pipeline's ramp is amortised the same way
         t1 = time.perf_counter()
-        host_last = host_steps(k)
-        hdt = (time.perf_counter() - t1) / k
+        host_last = host_steps(kh)
+        hdt = (time.perf_counter() - t1) / kh
         clf.detect_batch(frames_host, args.scale_factor, args.min_neighbors)
         t1 = time.perf_counter()
         for _ in range(k):
@@ -510,7 +549,7 @@ def main():
                            "what": f"the same steps with the {B} frames in pageable host memory (the reference's call shape, "
                                    "tools/detection/Cpp/main.cpp:27-45), pipelined through cc_detect_batch_submit / _collect like the headline: "
                                    "submit copies a pass's frames into the detector's pinned staging area (host threads) and issues ONE "
-                                   f"asynchronous H2D copy per pass on the front stream ({k} steps); synchronous_call_*: one cc_detect_batch per "
+                                   f"asynchronous H2D copy per pass on the front stream ({kh} steps); synchronous_call_*: one cc_detect_batch per "
                                    "step from the same host frames; never the headline `value`"}
         if not host_same:
             print("bench.py: rectangles from host frames differ from the resident-frame run", file=sys.stderr)
@@ -528,31 +567,11 @@ def main():
     eval_ms = tm["eval_ms"] / max(tm["eval_launches"], 1)
     frames_per_launch = tm["frames"] / max(tm["eval_launches"], 1)
     ach = eval_bytes_per_frame * frames_per_launch / (eval_ms * 1e-3) / 1e9 if eval_ms > 0 else 0.0
-    # Counter-based figures (HBM traffic, LDS / VALU busy) need their own rocprofv3 passes (tools/profile_bench.sh,
-    # tools/pmc_eval.sh): this run can only REPLAY the committed measurement, and does so only when that profile was
-    # taken from the very kernel sources this run executes (sha of the kernel files recorded next to the numbers).
     src_sha = kernel_source_sha16()
-    traffic = None
-    traffic_note = None
-    tfile = os.path.join(ROOT, "profiles", "r03_traffic_k_eval.json")
     kernel_name = "k_eval_spec" if spec_stages else ("k_eval_haar" if inf["feature_type"] == 0 else "k_eval_lbp")
-    if os.path.exists(tfile) and (W, H) == (1920, 1080) and abs(args.scale_factor - 1.1) < 1e-12:
-        tj = json.load(open(tfile))
-        if tj.get("kernel_src_sha16") == src_sha and tj.get("kernel") == kernel_name:
-            traffic = round(tj["hbm_bytes_per_frame"] * frames_per_launch)
-            traffic_note = {"replayed_from": "profiles/r03_traffic_k_eval.json", "profile_kernel_src_sha16": src_sha,
-                            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes, FETCH x2 (gfx950), scaled to this run's frames per launch"}
-        else:
-            traffic_note = {"refused": "profiles/r03_traffic_k_eval.json was measured on other kernel sources or another kernel "
-                                       f"({tj.get('kernel')}, {tj.get('kernel_src_sha16')} vs {kernel_name}, {src_sha}): re-run tools/profile_bench.sh"}
-    secondary = None
-    pfile = os.path.join(ROOT, "profiles", "r03_pmc_eval.json")
-    if os.path.exists(pfile) and (W, H) == (1920, 1080):
-        pj = json.load(open(pfile))
-        if pj.get("kernel_src_sha16") == src_sha and pj.get("kernel") == kernel_name:
-            secondary = {"lds_pipeline_busy": pj["lds_pipeline_busy"], "lds_bank_conflict_share": pj["lds_bank_conflict_share"],
-                         "valu_busy": pj["valu_busy"], "valu_active_counter_share": pj.get("valu_active_counter_share"), "replayed_from": "profiles/r03_pmc_eval.json (tools/pmc_eval.sh)",
-                         "profile_kernel_src_sha16": src_sha}
+    full_hd = (W, H) == (1920, 1080) and abs(args.scale_factor - 1.1) < 1e-12
+    lbp_suffix = "" if inf["feature_type"] == 0 else "_lbp"
+    traffic, traffic_note, secondary = replay_counters(lbp_suffix, kernel_name, os.path.basename(args.cascade), frames_per_launch, full_hd)
     # Secondary limiter measured IN THIS RUN: the rectangle-corner gathers the reference algorithm performs on the windows
     # its scan visits (frame 0: 4 corners of the variance rectangle + 4 per rectangle of every stump the window reaches;
     # LBP: 16 per stump), priced against the LDS gather peak (ds_read_b32: 128 B/clk/CU x 256 CUs x 2.4 GHz).

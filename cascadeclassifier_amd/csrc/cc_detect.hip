@@ -815,7 +815,7 @@ struct Plan {
     int n = 0;
     DevBuf<int4> d;
   };
-  std::map<int, std::unique_ptr<TileList>> other_tiles;  // tile lists for other tile heights (run-time specialised kernels)
+  std::map<int, std::unique_ptr<TileList>> other_tiles;  // tile lists of the specialised kernel's modules, key = tile_list_key(rows, step)
   DevBuf<ScaleDev> d_sd;
   DevBuf<int> d_resize_first, d_band_first, d_col_first, d_gridrow_first, d_diag_first, d_tcol_first, d_xofs, d_yofs;
   DevBuf<uint16_t> d_xw1, d_yw1;
@@ -863,6 +863,14 @@ using namespace ccamd;
 
 constexpr int kStageSlots = 3;  // staging slots for host frames (run_batch: why three)
 
+// One compiled module of the run-time specialised kernel: the tiles it covers (0 = all, 1 / 2 = the tiles of STEP-1 / STEP-2
+// scales) and the tile height it was compiled for.
+struct SpecCode {
+  std::vector<char> code;
+  int only_step = 0;
+  int tile_y = TILE_Y;
+};
+
 struct cc_detector {
   Cascade m;
   unsigned long long serial = 0;  // unique per created detector (tickets name their owner by it, not by address alone)
@@ -907,14 +915,22 @@ struct cc_detector {
   bool eval_pending[2] = {false, false};
   int overlap_front = 1;
   // run-time specialised cascade kernel (cc_detector_specialize); null = table-driven kernel
-  hipModule_t spec_mod = nullptr;
+  hipModule_t spec_mod = nullptr;   // the module that covers every tile, or the tiles of STEP-2 scales when spec_mod1 exists
   hipFunction_t spec_fn = nullptr;
+  // Optional second module for the tiles of STEP-1 scales (spec_modules: Haar kernels with 32-bit tiles compile one module per
+  // step, each with its own tile height and LDS request)
+  hipModule_t spec_mod1 = nullptr;
+  hipFunction_t spec_fn1 = nullptr;
+  size_t lds_spec1 = 0;
+  int spec_tile_y1 = TILE_Y;
+  int last_stamp_tiles = 0;  // CCAMD_DEBUG_STAMPS: tiles of the last pass (all launches)
+  int spec_only_step = 0;  // tiles the primary module covers: 0 = all, 2 = those of STEP-2 scales (then spec_fn1 covers STEP 1)
   int spec_stages = 0;
   // background build of the specialised module (cc_detector_specialize_async / CCAMD_AUTO_SPECIALIZE): a host thread
   // generates and compiles; the next detection call on the owning thread loads the module and switches over
   std::thread spec_thread;
   std::atomic<int> spec_bg_state{0};  // 0 idle, 1 building, 2 ready to install, 3 failed
-  std::vector<char> spec_bg_code;
+  std::vector<SpecCode> spec_bg_code;
   int spec_bg_stages = 0;
   int spec_bg_tmode = 0;
   std::string spec_bg_error;
@@ -973,6 +989,7 @@ struct cc_detector {
     if (front_stream) (void)hipStreamDestroy(front_stream);
     if (spec_thread.joinable()) spec_thread.join();
     if (spec_mod) (void)hipModuleUnload(spec_mod);
+    if (spec_mod1) (void)hipModuleUnload(spec_mod1);
     for (hipEvent_t e : {pass_done[0], pass_done[1], front_done[0], front_done[1], eval_done[0], eval_done[1], batch_begin})
       if (e) (void)hipEventDestroy(e);
     if (h_counts) (void)hipHostFree(h_counts);
@@ -2116,6 +2133,7 @@ static bool same_params(const cc_detect_params& a, const cc_detect_params& b) {
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2): the list is permuted so that the tiles
 // one XCD receives are neighbours in the image and share their halo rows/columns in that XCD's L2. Placement only changes
 // speed, never results.
+static int tile_list_key(int tile_y, int only_step) { return tile_y * 4 + only_step; }  // Plan::other_tiles
 static int debug_only_step() {  // timing experiments (CCAMD_DEBUG_ONLY_STEP=1|2): only the tiles of STEP-1 / STEP-2 scales are evaluated
   static const int v = []() {
     const char* e = std::getenv("CCAMD_DEBUG_ONLY_STEP");
@@ -2123,11 +2141,12 @@ static int debug_only_step() {  // timing experiments (CCAMD_DEBUG_ONLY_STEP=1|2
   }();
   return v;
 }
-static std::vector<int4> plan_tile_list(const std::vector<ScaleGeom>& geom, int tile_y) {
+static std::vector<int4> plan_tile_list(const std::vector<ScaleGeom>& geom, int tile_y, int only_step = 0) {
   std::vector<int4> tiles;
   for (size_t i = 0; i < geom.size(); i++) {
     const ScaleGeom& g = geom[i];
     if (debug_only_step() && g.ystep != debug_only_step()) continue;
+    if (only_step && g.ystep != only_step) continue;
     const int ntx = (g.nx + TILE_X - 1) / TILE_X, nty = (g.ny + tile_y - 1) / tile_y;
     for (int ty_ = 0; ty_ < nty; ty_++)
       for (int tx_ = 0; tx_ < ntx; tx_++) tiles.push_back(make_int4((int)i, tx_, ty_, 0));
@@ -2376,25 +2395,43 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.cand_count = d->d_counts[slot].p;
     A.cand_cap = d->cand_cap;
     A.stamps = nullptr;
-    // the tile list of the kernel that runs: the specialised kernel may have been compiled for another tile height
+    // The launches of this pass: one ahead-of-time kernel over the plan's tiles, or the specialised kernel's module(s), each
+    // over its own tile list (its tile height; the tiles of one step when there is a module per step). The lists were built
+    // by ensure_spec_tiles before the pass (never inside a graph capture).
+    struct EvalLaunch {
+      hipFunction_t fn;
+      size_t lds;
+      int n_tiles;
+      const int4* tiles;
+    };
+    EvalLaunch launches[2];
+    int n_launches = 0;
     const bool run_spec = d->spec_fn && d->m.max_nodes_per_tree <= 1;
-    int n_tiles = P->n_tiles;
-    const int4* tiles_p = P->d_tiles.p;
-    if (run_spec && d->spec_tile_y != TILE_Y) {
-      const auto it = P->other_tiles.find(d->spec_tile_y);  // built by ensure_spec_tiles before the pass (never inside a graph capture)
-      if (it == P->other_tiles.end() || !it->second)
-        return set_error(CC_ERR_HIP, "internal: no tile list for tiles of %d window rows", d->spec_tile_y);
-      n_tiles = it->second->n;
-      tiles_p = it->second->d.p;
-    }
-    if (std::getenv("CCAMD_DEBUG_STAMPS")) {  // timing experiments: per-block phase stamps of the cascade kernel
-      CC_HIP(d->d_stamps.ensure((size_t)n_tiles * (size_t)nf * STAMP_SLOTS));
-      CC_HIP(hipMemsetAsync(d->d_stamps.p, 0, (size_t)n_tiles * (size_t)nf * STAMP_SLOTS * sizeof(unsigned long long), st));
+    if (run_spec) {
+      const int want[2][2] = {{d->spec_tile_y, d->spec_only_step}, {d->spec_fn1 ? d->spec_tile_y1 : 0, 1}};
+      for (int i = 0; i < 2; i++) {
+        if (want[i][0] == 0) continue;
+        EvalLaunch L{i == 0 ? d->spec_fn : d->spec_fn1, i == 0 ? d->lds_spec : d->lds_spec1, P->n_tiles, P->d_tiles.p};
+        if (!(want[i][0] == TILE_Y && want[i][1] == 0)) {
+          const auto it = P->other_tiles.find(tile_list_key(want[i][0], want[i][1]));
+          if (it == P->other_tiles.end() || !it->second)
+            return set_error(CC_ERR_HIP, "internal: no tile list for tiles of %d window rows (step %d)", want[i][0], want[i][1]);
+          L.n_tiles = it->second->n;
+          L.tiles = it->second->d.p;
+        }
+        launches[n_launches++] = L;
+      }
+    } else
+      launches[n_launches++] = EvalLaunch{nullptr, d->lds, P->n_tiles, P->d_tiles.p};
+    size_t stamp_tiles = 0;
+    for (int i = 0; i < n_launches; i++) stamp_tiles += (size_t)launches[i].n_tiles;
+    if (std::getenv("CCAMD_DEBUG_STAMPS")) {  // timing experiments: per-block phase stamps of the cascade kernel (launch after launch)
+      CC_HIP(d->d_stamps.ensure(std::max<size_t>(stamp_tiles * (size_t)nf * STAMP_SLOTS, 1)));
+      CC_HIP(hipMemsetAsync(d->d_stamps.p, 0, stamp_tiles * (size_t)nf * STAMP_SLOTS * sizeof(unsigned long long), st));
       A.stamps = d->d_stamps.p;
     }
     A.dbg_codes = debug ? d->d_dbg_codes.p : nullptr;
     A.dbg_sums = debug ? d->d_dbg_sums.p : nullptr;
-    A.tiles = tiles_p;
     A.stumps1 = haar ? (const void*)d->d_haar1.p : (const void*)d->d_lbp1.p;
     A.stumps2 = haar ? (const void*)d->d_haar2.p : (const void*)d->d_lbp2.p;
     A.wstumps1 = d->d_haar1w.p ? (const void*)d->d_haar1w.p : A.stumps1;
@@ -2412,15 +2449,20 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     A.tree_root = d->d_tree_root.p;
     A.tree_leaf0 = d->d_tree_leaf0.p;
     A.leaves = d->d_leaves.p;
-    if (n_tiles) {
-      if (d->spec_fn && !A.trees) {
+    for (int i = 0; i < n_launches; i++) {
+      const EvalLaunch& L = launches[i];
+      if (L.n_tiles == 0) continue;
+      A.tiles = L.tiles;
+      if (L.fn) {
         void* params[] = {&A};
-        CC_HIP(hipModuleLaunchKernel(d->spec_fn, (unsigned)n_tiles, (unsigned)nf, 1, EVAL_THREADS, 1, 1, (unsigned)d->lds_spec, st, params, nullptr));
+        CC_HIP(hipModuleLaunchKernel(L.fn, (unsigned)L.n_tiles, (unsigned)nf, 1, EVAL_THREADS, 1, 1, (unsigned)L.lds, st, params, nullptr));
       } else if (haar)
-        hipLaunchKernelGGL(k_eval_haar, dim3(P->n_tiles, nf), dim3(EVAL_THREADS), d->lds, st, A);
+        hipLaunchKernelGGL(k_eval_haar, dim3(L.n_tiles, nf), dim3(EVAL_THREADS), L.lds, st, A);
       else
-        hipLaunchKernelGGL(k_eval_lbp, dim3(P->n_tiles, nf), dim3(EVAL_THREADS), d->lds, st, A);
+        hipLaunchKernelGGL(k_eval_lbp, dim3(L.n_tiles, nf), dim3(EVAL_THREADS), L.lds, st, A);
+      if (A.stamps) A.stamps += (size_t)L.n_tiles * (size_t)nf * STAMP_SLOTS;
     }
+    d->last_stamp_tiles = (int)stamp_tiles;
   }
   if (fs != st) {
     CC_HIP(hipEventRecord(d->eval_done[slot], st));
@@ -2437,7 +2479,7 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
   CC_HIP(hipGetLastError());
   if (const char* path = std::getenv("CCAMD_DEBUG_STAMPS")) {  // dump [n_tiles * nf][STAMP_SLOTS] u64 (overwritten per pass)
     CC_HIP(hipStreamSynchronize(st));
-    const int n_tiles_run = (d->spec_fn && d->m.max_nodes_per_tree <= 1 && d->spec_tile_y != TILE_Y) ? P->other_tiles[d->spec_tile_y]->n : P->n_tiles;
+    const int n_tiles_run = d->last_stamp_tiles;
     std::vector<unsigned long long> h((size_t)n_tiles_run * (size_t)nf * STAMP_SLOTS);
     CC_HIP(hipMemcpy(h.data(), d->d_stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (FILE* f = std::fopen(path, "wb")) {
@@ -2466,15 +2508,19 @@ static cc_status check_frame_args(const cc_detector* d, const uint8_t* frames, i
 // The specialised kernel may use another tile height than the ahead-of-time kernels: its tile list is built on first use,
 // with a synchronous copy -- so before the pass is launched, and never from inside a hipGraph capture.
 static cc_status ensure_spec_tiles(cc_detector* d, Plan* P) {
-  if (!d->spec_fn || d->m.max_nodes_per_tree > 1 || d->spec_tile_y == TILE_Y) return CC_OK;
-  std::unique_ptr<Plan::TileList>& tl = P->other_tiles[d->spec_tile_y];
-  if (tl) return CC_OK;
-  std::unique_ptr<Plan::TileList> fresh(new Plan::TileList);
-  const std::vector<int4> tv = plan_tile_list(P->geom, d->spec_tile_y);
-  fresh->n = (int)tv.size();
-  CC_HIP(fresh->d.ensure(std::max<size_t>(tv.size(), 1)));
-  if (!tv.empty()) CC_HIP(hipMemcpy(fresh->d.p, tv.data(), tv.size() * sizeof(int4), hipMemcpyHostToDevice));
-  tl = std::move(fresh);
+  if (!d->spec_fn || d->m.max_nodes_per_tree > 1) return CC_OK;
+  const int want[2][2] = {{d->spec_tile_y, d->spec_only_step}, {d->spec_fn1 ? d->spec_tile_y1 : 0, 1}};
+  for (const auto& w : want) {
+    if (w[0] == 0 || (w[0] == TILE_Y && w[1] == 0)) continue;  // no such module / the plan's own list serves it
+    std::unique_ptr<Plan::TileList>& tl = P->other_tiles[tile_list_key(w[0], w[1])];
+    if (tl) continue;
+    std::unique_ptr<Plan::TileList> fresh(new Plan::TileList);
+    const std::vector<int4> tv = plan_tile_list(P->geom, w[0], w[1]);
+    fresh->n = (int)tv.size();
+    CC_HIP(fresh->d.ensure(std::max<size_t>(tv.size(), 1)));
+    if (!tv.empty()) CC_HIP(hipMemcpy(fresh->d.p, tv.data(), tv.size() * sizeof(int4), hipMemcpyHostToDevice));
+    tl = std::move(fresh);
+  }
   return CC_OK;
 }
 
@@ -2588,7 +2634,7 @@ static cc_status stage_host_frames(cc_detector* d, const uint8_t* src, int nf, i
   static const int want_threads = []() {
     if (const char* e = std::getenv("CCAMD_STAGE_THREADS")) return std::max(1, std::atoi(e));
     const unsigned hc = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(4u, hc / 2));
+    return (int)std::max(1u, std::min(8u, hc / 2));  // 64 Full-HD frames per step: 2 threads 18.2, 4 17.9, 8 17.85 ms (resident frames 17.44)
   }();
   const size_t total = fs * (size_t)nf;
   const int nt = (int)std::min<size_t>((size_t)std::min(want_threads, nf), std::max<size_t>(1, total >> 21));  // >= 2 MB per thread
@@ -2693,7 +2739,7 @@ static cc_status run_batch(cc_detector* d, const uint8_t* frames, int on_device,
     };
     auto key_now = [&]() {
       return std::vector<const void*>{d->d_frames.p, d->h_frame, d->d_pyr.p, d->d_integ[0].p, d->d_hbuf.p, d->d_diag.p, d->d_tseg.p, d->d_masks[0].p, d->d_cands[0].p,
-                                      d->d_out[0].p, d->d_counts[0].p, d->h_counts, (const void*)d->spec_fn, (const void*)d->stream,
+                                      d->d_out[0].p, d->d_counts[0].p, d->h_counts, (const void*)d->spec_fn, (const void*)d->spec_fn1, (const void*)d->stream,
                                       (const void*)(size_t)d->cand_cap, (const void*)(size_t)d->wave_below, (const void*)(size_t)(d->stop_after + 16)};
     };
     if (d->eval_pending[0] || d->eval_pending[1]) {  // a batch call may still be using the buffers on the other stream
@@ -2988,20 +3034,44 @@ static const char kSpecPrelude[] =
     "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
 
 // Compiles `src` for `arch`; identical (source, options) pairs are served from a per-process cache.
-// Window rows per tile of a run-time specialised kernel (its -DCC_TILE_Y). LBP kernels whose STEP-2 tiles hold 16-bit entries
-// take 16 rows (64 x 16 windows per block of 256 threads): a tile's halo rows are staged per 16 instead of per 8 window
-// rows, the per-block work (barrier rounds, counters, the wave phase's window collection) is paid once per 1024 windows, and
-// the late stages find twice the windows per block to fill their wavefronts with; at 22.7 KB per block seven blocks still fit
-// a CU. Measured on the stock LBP cascade, ms per 32 Full-HD frames alone: 8 rows 4.84, 12 rows 4.47, 16 rows 4.38
-// (tools/r4_e.sh). Haar kernels stay at the library's 8 (31 KB tiles: 16 rows leave 3 blocks per CU, 9.5 against 7.9 ms).
-static int spec_tile_rows(const Cascade& m, int tmode) {
-  int ty = (m.feature_type == CC_FEATURE_LBP && tmode == TILE_16) ? 16 : TILE_Y;
-  if (const char* e = std::getenv("CCAMD_SPEC_TILE_Y")) ty = std::atoi(e);  // tuning
-  if (ty < EVAL_WAVES || ty > 32 || ty % EVAL_WAVES != 0 || tmode == TILE_PAIR16) ty = TILE_Y;
-  return ty;
+// The modules a run-time specialised kernel is compiled as: which tiles each covers and its tile height (-DCC_TILE_Y).
+// * LBP kernels whose STEP-2 tiles hold 16-bit entries: ONE module, 20 window rows per tile (64 x 20 windows per block of 256
+//   threads). A tile's halo rows are staged per 20 instead of per 8 window rows, the per-block work (barrier rounds,
+//   counters, the wave phase's window collection) is paid once per 1 280 windows, and the late stages find 2.5 x the windows per
+//   block to fill their wavefronts with; at 26 KB per block six blocks fit a CU (6 wavefronts per SIMD: 80 VGPRs).
+//   Stock LBP cascade, ms per 32 Full-HD frames alone (tools/r4_g.sh): 8 rows 4.90, 12 rows 4.25, 16 rows 3.96, 20 rows 3.78,
+//   24 rows 3.85, 32 rows 4.12 (each at its best register budget).
+// * Haar kernels with 32-bit tiles: TWO modules, one per step -- 12 rows for the STEP-1 tiles, 8 for the STEP-2 tiles. A
+//   STEP-1 tile is a third of a STEP-2 tile (12.7 KB against 24 KB), but one launch requests the larger of the two for every
+//   block; in a launch of their own the STEP-1 tiles run at 6 blocks per CU. ms per 32 Full-HD frames alone, one run
+//   (tools/r4_h.sh): one module at 8 rows 8.35; two modules at 8 / 8 rows 7.82, 12 / 8 rows 7.32, 12 / 12 rows 7.49,
+//   16 / 12 rows 7.77, 12 / 16 rows 8.11 (STEP-1 / STEP-2; a 32-bit STEP-2 tile of 12 rows leaves 4 blocks per CU).
+// * everything else (pair tile, Haar with 16-bit tiles): one module at the library's 8 rows.
+// CCAMD_SPEC_TILE_Y sets every module's rows, CCAMD_SPEC_TILE_Y1 / _Y2 the STEP-1 / STEP-2 module's, CCAMD_SPEC_ONE_MODULE=1
+// forces a single module (tuning).
+struct SpecModulePlan {
+  int only_step, tile_y;
+};
+static std::vector<SpecModulePlan> spec_modules(const Cascade& m, int tmode) {
+  auto valid = [&](int ty) { return ty >= EVAL_WAVES && ty <= 32 && ty % EVAL_WAVES == 0; };
+  auto env_rows = [&](const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    const int v = e ? std::atoi(e) : dflt;
+    return valid(v) ? v : dflt;
+  };
+  // (cascades with tilted features keep the library's tile height: their records and generated offsets carry the distance
+  // between the sum tile and the tilted tile behind it, which depends on the tile's rows)
+  if (tmode == TILE_PAIR16 || m.has_tilted) return {{0, TILE_Y}};
+  const bool lbp16 = m.feature_type == CC_FEATURE_LBP && tmode == TILE_16;
+  const bool haar32 = tmode == TILE_32 && m.feature_type == CC_FEATURE_HAAR;
+  const bool rows_given = std::getenv("CCAMD_SPEC_TILE_Y") != nullptr;
+  const int all = env_rows("CCAMD_SPEC_TILE_Y", lbp16 ? 20 : TILE_Y);
+  const bool two = (haar32 || std::getenv("CCAMD_SPEC_TWO_MODULES")) && !std::getenv("CCAMD_SPEC_ONE_MODULE");
+  if (!two) return {{0, all}};
+  return {{2, env_rows("CCAMD_SPEC_TILE_Y2", all)}, {1, env_rows("CCAMD_SPEC_TILE_Y1", (haar32 && !rows_given) ? 12 : all)}};
 }
 
-static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, bool lbp, int tmode, int tile_y, int win_w, int win_h, std::vector<char>& code) {
+static cc_status compile_specialised(const std::string& src, const std::string& arch, int n_stages, bool lbp, int tmode, int tile_y, int only_step, int win_w, int win_h, std::vector<char>& code) {
   const bool tile16 = tmode == TILE_16;
   static std::mutex mu;
   static std::map<std::string, std::vector<char>> cache;
@@ -3009,10 +3079,13 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
   const std::string o_ty = "-DCC_TILE_Y=" + std::to_string(tile_y), o_th = "-DCC_EVAL_THREADS=" + std::to_string(EVAL_THREADS);
   // same code generation rules as the ahead-of-time build (Makefile): no FMA contraction, no fast-math
   // register budget = the occupancy the LDS footprint allows: 5 blocks per CU with the 32-bit tile, 7-8 with the 16-bit one
-  std::string o_w = "-DCC_EVAL_MIN_WAVES_PER_EU=" + std::to_string(tile16 ? 7 : CC_EVAL_MIN_WAVES_PER_EU);
+  // (16-bit tiles of >= 20 rows: 26 KB per block = 6 blocks per CU)
+  std::string o_w = "-DCC_EVAL_MIN_WAVES_PER_EU=" + std::to_string(tile16 ? (tile_y >= 20 ? 6 : 7) : CC_EVAL_MIN_WAVES_PER_EU);
+  const std::string o_step = "-DCC_ONLY_STEP=" + std::to_string(only_step);
   if (const char* e = std::getenv("CCAMD_SPEC_WAVES_PER_EU")) o_w = "-DCC_EVAL_MIN_WAVES_PER_EU=" + std::to_string(std::max(1, std::min(8, std::atoi(e))));  // tuning
   const std::string o_w0 = "-DCC_SPEC_W0=" + std::to_string(win_w), o_h0 = "-DCC_SPEC_H0=" + std::to_string(win_h);  // tile geometry folds to constants
   std::vector<const char*> optv = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", o_k.c_str(), o_ty.c_str(), o_th.c_str(), o_w.c_str(), o_w0.c_str(), o_h0.c_str()};
+  if (only_step) optv.push_back(o_step.c_str());
   if (lbp) optv.push_back("-DCC_SPEC_LBP");
   if (tile16) optv.push_back("-DCC_SPEC_TILE16");
   if (tmode == TILE_PAIR16) optv.push_back("-DCC_SPEC_PAIR16");
@@ -3147,7 +3220,7 @@ static cc_status compile_specialised(const std::string& src, const std::string& 
 
 // Host half of the specialisation: source for the first stages (whole stages within the code-size budget) compiled for
 // `arch`. No device calls: safe on a background thread.
-static cc_status spec_build(const Cascade& m, int n_stages, const std::string& arch, std::vector<char>& code, int& k_out, int& tmode_out) {
+static cc_status spec_build(const Cascade& m, int n_stages, const std::string& arch, std::vector<SpecCode>& codes, int& k_out, int& tmode_out) {
   if (m.max_nodes_per_tree > 1) return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: stump cascades only");
   int k = 0, stumps = 0;
   int budget = 320;  // instruction cache: more stages measured no faster, 12 stages slower
@@ -3165,72 +3238,116 @@ static cc_status spec_build(const Cascade& m, int n_stages, const std::string& a
   src.replace(pos, marker.size(), spec_stage_source(m, k, tmode));
   k_out = k;
   tmode_out = tmode;
-  return compile_specialised(src, arch, k, m.feature_type == CC_FEATURE_LBP, tmode, spec_tile_rows(m, tmode), m.win_w, m.win_h, code);
+  codes.clear();
+  for (const SpecModulePlan& mp : spec_modules(m, tmode)) {
+    SpecCode c;
+    c.only_step = mp.only_step;
+    c.tile_y = mp.tile_y;
+    const cc_status st = compile_specialised(src, arch, k, m.feature_type == CC_FEATURE_LBP, tmode, mp.tile_y, mp.only_step, m.win_w, m.win_h, c.code);
+    if (st != CC_OK) return st;
+    codes.push_back(std::move(c));
+  }
+  return CC_OK;
 }
 
 // Device half: load the code object and make it the detector's cascade kernel. Owning thread only.
-static cc_status spec_install(cc_detector* d, const std::vector<char>& code, int k, int tmode) {
-  retire_foreign(d);  // a pass still unfetched was launched with the old kernel (and its tile list): fetch it before the switch
-  hipModule_t mod = nullptr;
-  hipFunction_t fn = nullptr;
-  CC_HIP(hipModuleLoadData(&mod, code.data()));
-  if (hipModuleGetFunction(&fn, mod, "k_eval_spec") != hipSuccess) {
-    (void)hipModuleUnload(mod);
-    return set_error(CC_ERR_HIP, "cc_detector_specialize: entry point not found in the compiled module");
-  }
-  const int ty = spec_tile_rows(d->m, tmode);
+static cc_status spec_install(cc_detector* d, const std::vector<SpecCode>& codes, int k, int tmode) {
+  if (codes.empty() || codes.size() > 2) return set_error(CC_ERR_HIP, "cc_detector_specialize: %zu modules", codes.size());
+  retire_foreign(d);  // a pass still unfetched was launched with the old kernel (and its tile lists): fetch it before the switch
   const bool haar_k = d->m.feature_type == CC_FEATURE_HAAR;
-  size_t lds_spec = d->lds;
-  if (tmode == TILE_32) {
-    const TileGeom<1> G1(d->m.win_w, d->m.win_h, ty);
-    const TileGeom<2> G2(d->m.win_w, d->m.win_h, ty);
-    const int words = debug_only_step() == 1 ? G1.words() : debug_only_step() == 2 ? G2.words() : std::max(G1.words(), G2.words());
-    lds_spec = eval_lds_bytes(words, d->m.has_tilted, haar_k, ty) + d->lds_extra;
-  } else if (tmode == TILE_16) {  // STEP-1 tile in 32 bits, STEP-2 tile in 16 bits
-    const TileGeom<1> G1(d->m.win_w, d->m.win_h, ty);
-    const TileGeom16 G2(d->m.win_w, d->m.win_h, ty);
-    lds_spec = eval_lds_bytes(std::max(G1.words(), G2.words()), false, haar_k, ty) + d->lds_extra;
-  } else if (tmode == TILE_PAIR16) {  // STEP-2 tile of window pairs, with partial sums for both windows of a slot
-    const TileGeom<1> G1(d->m.win_w, d->m.win_h);
-    const TileGeomP G2(d->m.win_w, d->m.win_h);
-    lds_spec = std::max(eval_lds_bytes(G1.words(), false), eval_lds_bytes_pair(G2.words())) + d->lds_extra;
-    if (!d->d_haar_p16.p) {
-      std::vector<HaarStumpP16> tp, tw;
-      build_haar_stumps_p16(d->m, tp);
-      // wave phase: the stage's stumps in the bank-aware order computed for this geometry's offsets (the records carry
-      // their stump's index in `pad`)
-      std::vector<HaarStumpDev> geo;
-      build_haar_stumps_at(d->m, geo, [&](int y, int x) { return G2.at(y, x); }, 0);
-      const std::vector<HaarStumpDev> order = d->wave_below > 0 && !std::getenv("CCAMD_NO_WAVE_SCHEDULE") ? schedule_for_wave_phase(d->m, geo) : geo;
-      tw.reserve(order.size());
-      for (const HaarStumpDev& r : order) tw.push_back(tp[(size_t)r.pad]);
-      CC_HIP(d->d_haar_p16.upload(tp, d->stream));
-      CC_HIP(d->d_haar_p16w.upload(tw, d->stream));
-      CC_HIP(hipStreamSynchronize(d->stream));
-    }
-  }
-  if (lds_spec > 64 * 1024) {  // same opt-in as the ahead-of-time kernels (cc_detector_create)
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec);
-    if (e != hipSuccess) {
+  struct Loaded {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    size_t lds = 0;
+    int tile_y = TILE_Y, only_step = 0;
+  };
+  std::vector<Loaded> L;
+  auto unload_all = [&]() {
+    for (Loaded& x : L)
+      if (x.mod) (void)hipModuleUnload(x.mod);
+  };
+  for (const SpecCode& c : codes) {
+    Loaded x;
+    x.tile_y = c.tile_y;
+    x.only_step = c.only_step;
+    if (hipModuleLoadData(&x.mod, c.code.data()) != hipSuccess || hipModuleGetFunction(&x.fn, x.mod, "k_eval_spec") != hipSuccess) {
       (void)hipGetLastError();
-      (void)hipModuleUnload(mod);
-      return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: %zu bytes of LDS per tile cannot be requested for a run-time module (%s)",
-                       d->lds, hipGetErrorString(e));
+      if (x.mod) (void)hipModuleUnload(x.mod);
+      unload_all();
+      return set_error(CC_ERR_HIP, "cc_detector_specialize: the compiled module does not load or has no entry point");
     }
-  }
-  if (std::getenv("CCAMD_TRACE_HOST")) {  // what the specialised kernel's footprint allows per CU
-    int nb = 0;
-    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, EVAL_THREADS, lds_spec) != hipSuccess) (void)hipGetLastError();
-    std::fprintf(stderr, "[ccamd host] specialised kernel: tile mode %d, %zu bytes of LDS per block, %d resident blocks per CU\n", tmode, lds_spec, nb);
+    const int ty = c.tile_y;
+    // tiles this module stages: of the step(s) it covers (CCAMD_DEBUG_ONLY_STEP narrows a single module's request for timing runs)
+    const int step = c.only_step ? c.only_step : debug_only_step();
+    x.lds = d->lds;
+    if (tmode == TILE_32) {
+      const TileGeom<1> G1(d->m.win_w, d->m.win_h, ty);
+      const TileGeom<2> G2(d->m.win_w, d->m.win_h, ty);
+      const int words = step == 1 ? G1.words() : step == 2 ? G2.words() : std::max(G1.words(), G2.words());
+      x.lds = eval_lds_bytes(words, d->m.has_tilted, haar_k, ty) + d->lds_extra;
+    } else if (tmode == TILE_16) {  // STEP-1 tile in 32 bits, STEP-2 tile in 16 bits
+      const TileGeom<1> G1(d->m.win_w, d->m.win_h, ty);
+      const TileGeom16 G2(d->m.win_w, d->m.win_h, ty);
+      x.lds = eval_lds_bytes(std::max(G1.words(), G2.words()), false, haar_k, ty) + d->lds_extra;
+    } else if (tmode == TILE_PAIR16) {  // STEP-2 tile of window pairs, with partial sums for both windows of a slot
+      const TileGeom<1> G1(d->m.win_w, d->m.win_h);
+      const TileGeomP G2(d->m.win_w, d->m.win_h);
+      x.lds = std::max(eval_lds_bytes(G1.words(), false), eval_lds_bytes_pair(G2.words())) + d->lds_extra;
+      if (!d->d_haar_p16.p) {
+        std::vector<HaarStumpP16> tp, tw;
+        build_haar_stumps_p16(d->m, tp);
+        // wave phase: the stage's stumps in the bank-aware order computed for this geometry's offsets (the records carry
+        // their stump's index in `pad`)
+        std::vector<HaarStumpDev> geo;
+        build_haar_stumps_at(d->m, geo, [&](int y, int x2) { return G2.at(y, x2); }, 0);
+        const std::vector<HaarStumpDev> order = d->wave_below > 0 && !std::getenv("CCAMD_NO_WAVE_SCHEDULE") ? schedule_for_wave_phase(d->m, geo) : geo;
+        tw.reserve(order.size());
+        for (const HaarStumpDev& r : order) tw.push_back(tp[(size_t)r.pad]);
+        CC_HIP(d->d_haar_p16.upload(tp, d->stream));
+        CC_HIP(d->d_haar_p16w.upload(tw, d->stream));
+        CC_HIP(hipStreamSynchronize(d->stream));
+      }
+    }
+    if (x.lds > 64 * 1024) {  // same opt-in as the ahead-of-time kernels (cc_detector_create)
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x.lds);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipModuleUnload(x.mod);
+        unload_all();
+        return set_error(CC_ERR_UNSUPPORTED, "cc_detector_specialize: %zu bytes of LDS per tile cannot be requested for a run-time module (%s)",
+                         x.lds, hipGetErrorString(e));
+      }
+    }
+    if (std::getenv("CCAMD_TRACE_HOST")) {  // what the specialised kernel's footprint allows per CU
+      int nb = 0;
+      if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x.fn, EVAL_THREADS, x.lds) != hipSuccess) (void)hipGetLastError();
+      std::fprintf(stderr, "[ccamd host] specialised kernel: tile mode %d, tiles of step %d (0 = all), %d window rows, %zu bytes of LDS per block, %d resident blocks per CU\n",
+                   tmode, c.only_step, ty, x.lds, nb);
+    }
+    L.push_back(x);
   }
   CC_HIP(hipStreamSynchronize(d->stream));
   if (d->spec_mod) (void)hipModuleUnload(d->spec_mod);
-  d->spec_mod = mod;
-  d->spec_fn = fn;
+  if (d->spec_mod1) (void)hipModuleUnload(d->spec_mod1);
+  d->spec_mod1 = nullptr;
+  d->spec_fn1 = nullptr;
+  // the module for all tiles or for the STEP-2 tiles is the primary one; a STEP-1 module, if any, the second
+  const Loaded* prim = &L[0];
+  const Loaded* sec = L.size() > 1 ? &L[1] : nullptr;
+  if (sec && prim->only_step == 1) std::swap(prim, sec);
+  d->spec_mod = prim->mod;
+  d->spec_fn = prim->fn;
+  d->lds_spec = prim->lds;
+  d->spec_tile_y = prim->tile_y;
+  d->spec_only_step = prim->only_step;
+  if (sec) {
+    d->spec_mod1 = sec->mod;
+    d->spec_fn1 = sec->fn;
+    d->lds_spec1 = sec->lds;
+    d->spec_tile_y1 = sec->tile_y;
+  }
   d->spec_stages = k;
-  d->lds_spec = lds_spec;
   d->spec_tmode = tmode;
-  d->spec_tile_y = ty;
   return CC_OK;
 }
 
@@ -3262,7 +3379,7 @@ static cc_status spec_start_background(cc_detector* d, int n_stages) {
   d->spec_bg_error.clear();
   d->spec_bg_state.store(1, std::memory_order_release);
   d->spec_thread = std::thread([d, n_stages, arch]() {
-    std::vector<char> code;
+    std::vector<SpecCode> code;
     int k = 0;
     int tmode = 0;
     const cc_status s2 = spec_build(d->m, n_stages, arch, code, k, tmode);
@@ -3547,15 +3664,16 @@ cc_status cc_detector_specialize(cc_detector* d, int n_stages) {
   if (n_stages <= 0) {  // back to the table-driven kernel
     CC_HIP(hipStreamSynchronize(d->stream));
     if (d->spec_mod) (void)hipModuleUnload(d->spec_mod);
-    d->spec_mod = nullptr;
-    d->spec_fn = nullptr;
+    if (d->spec_mod1) (void)hipModuleUnload(d->spec_mod1);
+    d->spec_mod = d->spec_mod1 = nullptr;
+    d->spec_fn = d->spec_fn1 = nullptr;
     d->spec_stages = 0;
     return CC_OK;
   }
   std::string arch;
   st = device_arch(d->device, arch);
   if (st != CC_OK) return st;
-  std::vector<char> code;
+  std::vector<SpecCode> code;
   int k = 0;
   int tmode = 0;
   st = spec_build(d->m, n_stages, arch, code, k, tmode);
@@ -3575,12 +3693,13 @@ int cc_detector_specialized_stages(const cc_detector* d) { return d ? d->spec_st
 
 cc_status cc_cascade_compile_specialized(const cc_cascade* c, int n_stages, const char* arch, size_t* code_bytes) {
   if (!c || !arch || !code_bytes) return set_error(CC_ERR_INVALID_ARG, "cc_cascade_compile_specialized: null argument");
-  std::vector<char> code;
+  std::vector<SpecCode> code;
   int k = 0;
   int tmode = 0;
   const cc_status st = spec_build(c->m, std::max(1, n_stages), arch, code, k, tmode);
   if (st != CC_OK) return st;
-  *code_bytes = code.size();
+  *code_bytes = 0;
+  for (const SpecCode& m : code) *code_bytes += m.code.size();  // all modules (Haar: one per step)
   return CC_OK;
 }
 

@@ -158,7 +158,11 @@ CC_API cc_status cc_detect_batch_device_only(cc_detector* d, const uint8_t* fram
  * batch run under the cascade kernel of the old one and the host side of the old batch's last pass (copy-back, grouping)
  * under the device side of the new one -- the two parts of a synchronous call that nothing overlaps. At most one batch
  * is left unfetched inside the detector: a later submit (or any other detection call) fetches it first; results stay in
- * the ticket until collect. Frames (device or host memory) must stay valid until the batch is collected. collect frees
+ * the ticket until collect. DEVICE frames must stay valid until the batch is collected; HOST frames are copied into the
+ * detector's pinned staging area inside submit (three slots; the copy to the device is asynchronous on the front stream and a
+ * pass's frames are staged one pass ahead of its kernels) and may be reused as soon as submit returns -- unless they already
+ * live in pinned memory (hipHostMalloc / hipHostRegister): those are copied straight from the caller's buffer and must stay valid
+ * until the batch is collected. collect frees
  * the ticket, except when it returns CC_ERR_BUFFER_TOO_SMALL (offsets[n_frames] then holds the count: collect again with
  * room for it). cc_detect_batch_discard ends a ticket whose results are not wanted (it waits for the batch's last pass;
  * NULL is accepted); a ticket that is neither collected nor discarded leaks. A ticket is ended only by the detector that
@@ -292,18 +296,26 @@ CC_API int cc_eval_max_cat_count(const cc_evaluator* e); /* 0 Haar, 256 LBP */
 CC_API int cc_eval_feature_size(const cc_evaluator* e);  /* 1 */
 /* Haar: rects int32[3][4], weights float[3], *tilted; LBP: rects[0] = one cell (x y w h), weights/tilted untouched. */
 CC_API cc_status cc_eval_feature_geometry(const cc_evaluator* e, int fi, int32_t* rects, float* weights, int* tilted);
-/* img: win_h rows of win_w bytes, row_stride bytes apart. idx < max_samples. */
+/* img: win_h rows of win_w bytes, row_stride bytes apart. idx < max_samples.
+ * The call does no device work (the trainer makes it per candidate window, cascadeclassifier.cpp:340-347): the pixels are
+ * queued -- a later image for the same idx replaces the queued one; the queue reaches the device, runs of consecutive indices
+ * per launch, before anything reads stored samples there -- and the integral(s) and norm factor of THIS window are mirrored
+ * on the host, from which cc_eval_calc / cc_eval_calc_list answer for idx until the next cc_eval_set_image(s) (SURVEY.md 8b:
+ * "scalar, host-mirror fast path"). The mirror's values are bit-identical to the device's for every catalog feature
+ * (tests/test_gpu_eval.py::test_host_mirror_of_the_last_set_window_equals_the_device). */
 CC_API cc_status cc_eval_set_image(cc_evaluator* e, const uint8_t* img, size_t row_stride, uint8_t cls_label, int idx);
 /* n images of win_w x win_h, densely packed, stored at idx first_idx..first_idx+n-1; labels may be NULL (labels kept). */
 CC_API cc_status cc_eval_set_images(cc_evaluator* e, const uint8_t* imgs, int n, int first_idx, const uint8_t* labels);
 /* Host array of max_samples floats (the reference's `cls` Mat; o_cvcascadeboosttraindata.cpp:238-239 wraps it). */
 CC_API const float* cc_eval_labels(const cc_evaluator* e);
-/* Scalar operator()(featureIdx, sampleIdx): one device evaluation (slow; prefer the batch / list forms). */
+/* Scalar operator()(featureIdx, sampleIdx). For the sample set last by cc_eval_set_image: answered from its host mirror, no
+ * launch (~20 ns). Any other sample: one device evaluation (slow; prefer the batch / list forms). */
 CC_API cc_status cc_eval_calc(cc_evaluator* e, int fi, int si, float* out);
 /* out[k] = evaluator(feature_idx[k], si) for an arbitrary list of features and ONE stored sample, in one launch: the call
  * shape of the trainer's stage prediction on a freshly set window (CvCascadeBoostTree::predict ->
  * CvCascadeBoostTrainData::getVarValue, o_cvcascadeboosttree.cpp:16-39, o_cvcascadeboosttraindata.cpp:484-488), which asks
- * for the cascade's features one by one. The C++ adaptor batches those scalar calls through this entry point. */
+ * for the cascade's features one by one. For the sample set last by cc_eval_set_image the values come from its host mirror;
+ * the C++ adaptor batches scalar calls for other samples through this entry point. */
 CC_API cc_status cc_eval_calc_list(cc_evaluator* e, const int32_t* feature_idx, int n_feats, int si, float* out);
 /* out[(fi - fi_begin) * n_samples + s] = evaluator(fi, sample_idx ? sample_idx[s] : s); out is HOST memory unless
  * out_on_device != 0 (then it is memory of the evaluator's device). */

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import cascadeclassifier_amd as cc
+from cascadeclassifier_amd import _lib as L
 from oracle import oracle as orc
 from tests import cascade_factory as cf
 from tests.util import frame_natural, frame_uniform

@@ -3,9 +3,9 @@
 # Haar tile rows per step, the fast variance norm factor A/B, host-frame staging threads.
 O=gpurun_out/r4_g.txt
 LBP="--cascade data/lbpcascade_frontalface.xml --specialize 20"
-timeout -k 10 1100 python -m pytest tests -x -v -m gpu --timeout 240 > gpurun_out/r4_t2.log 2>&1
-tail -n 4 gpurun_out/r4_t2.log
-grep -q " passed" gpurun_out/r4_t2.log && ! grep -q "failed\|Timeout" gpurun_out/r4_t2.log || exit 1
+timeout -k 10 1100 python -m pytest tests/test_gpu_specialize.py tests/test_gpu_split.py tests/test_host_logic.py tests/test_host_sanitizers.py tests/test_oracle_detect.py tests/test_oracle_kats.py -x -v -m gpu --timeout 240 > gpurun_out/r4_t3.log 2>&1
+tail -n 4 gpurun_out/r4_t3.log
+grep -q " passed" gpurun_out/r4_t3.log && ! grep -q "failed\|Timeout" gpurun_out/r4_t3.log || exit 1
 {
 echo "### LBP: tile rows x register budget"
 for ty in 8 12 16 20 24 32; do for w in 5 6 7; do echo "CCAMD_SPEC_TILE_Y=$ty CCAMD_SPEC_WAVES_PER_EU=$w -- $LBP"; done; done | bash tools/env_sweep.sh

@@ -23,7 +23,7 @@ if [ "$(grep -c 'reinterpret_cast<const unsigned short\*>(b)' $out.hip)" -gt 1 ]
 # pair tile (CCAMD_SPEC_PAIR16=1): the generated source specialises spec_stage_pair
 if grep -q 'void spec_stage_pair<2>' $out.hip; then t16="-DCC_SPEC_PAIR16"; fi
 # LBP kernels with 16-bit tiles are compiled for tiles of 16 window rows (spec_tile_rows in cc_detect.hip)
-if [ -n "$lbp" ] && [ "$t16" = "-DCC_SPEC_TILE16" ] && [ -z "$CC_TILE_Y" ]; then CC_TILE_Y=${CCAMD_SPEC_TILE_Y:-16}; fi
+if [ -n "$lbp" ] && [ "$t16" = "-DCC_SPEC_TILE16" ] && [ -z "$CC_TILE_Y" ]; then CC_TILE_Y=${CCAMD_SPEC_TILE_Y:-20}; dw=6; fi
 W=$(grep -o '<width>[0-9]*' "$xml" | head -1 | grep -o '[0-9]*'); H=$(grep -o '<height>[0-9]*' "$xml" | head -1 | grep -o '[0-9]*')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -include hip/hip_runtime.h -DCC_SPEC_STAGES=$k \
   -DCC_TILE_Y=${CC_TILE_Y:-8} -DCC_EVAL_THREADS=${CC_EVAL_THREADS:-256} -DCC_EVAL_MIN_WAVES_PER_EU=${WAVES:-$dw} -DCC_SPEC_W0=$W -DCC_SPEC_H0=$H $lbp $t16 "$@" \

@@ -9,6 +9,7 @@ import shutil
 import sys
 
 tag, dst_prefix = sys.argv[1], sys.argv[2]
+suffix = sys.argv[3] if len(sys.argv) > 3 else ""  # "_lbp": the traffic file of another cascade's kernel (profiles/<round>_traffic_k_eval_lbp.json)
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]  # a tag may have been profiled more than once
@@ -42,9 +43,10 @@ for k, v in summary["kernels"].items():
         fpl = summary["bench"]["roofline"]["frames_per_launch"]
         json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_bench.sh {tag}), MI355X, bench.py "
                              "--cpu-frames 0 --steps 2 --warmup 1, CCAMD_NO_FRONT_OVERLAP=1 (counters are device-wide)",
-                   "kernel": k, "kernel_src_sha16": summary["kernel_src_sha16"], "frames_per_launch": fpl, "fetch_correction": 2.0,
+                   "kernel": k, "cascade": summary["bench"]["config"]["cascade"].split(" ")[0], "kernel_src_sha16": summary["kernel_src_sha16"],
+                   "frames_per_launch": fpl, "fetch_correction": 2.0,
                    "fetch_size_kb_raw_per_launch": v["FETCH_SIZE_KB_per_launch_raw"], "write_size_kb_raw_per_launch": v["WRITE_SIZE_KB_per_launch_raw"],
                    "hbm_bytes_per_frame": (2.0 * v["FETCH_SIZE_KB_per_launch_raw"] + v["WRITE_SIZE_KB_per_launch_raw"]) * 1024 / fpl},
-                  open(f"profiles/{dst_prefix.split('_')[0]}_traffic_k_eval.json", "w"), indent=1)
+                  open(f"profiles/{dst_prefix.split('_')[0]}_traffic_k_eval{suffix}.json", "w"), indent=1)
 json.dump(summary, open(f"profiles/{dst_prefix}_summary.json", "w"), indent=1)
 print(json.dumps(summary["kernels"], indent=1))
