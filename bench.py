@@ -85,6 +85,21 @@ def corner_reads_frame0(clf, frame, scale_factor):
     return int(reads[vis != 0].sum())
 
 
+def cascade_kernel_launches(tm, spec, feature_type, plan, chan_bytes):
+    """The cascade kernel's launches of one pass as a kernel trace lists them, with each one's average duration (HIP events
+    of this run) and algorithmic bytes per frame (every integral entry of the scales it covers, once). A run-time
+    specialised Haar kernel is one module per step: k_eval_spec_step2 over the tiles of STEP-2 scales, then k_eval_spec_step1."""
+    passes = max(tm["eval_launches"], 1)
+    total = tm["eval_ms"] / passes
+    px = (plan["w"] + 1).astype(np.int64) * (plan["h"] + 1)
+    b1, b2 = int(px[plan["ystep"] == 1].sum()) * chan_bytes, int(px[plan["ystep"] == 2].sum()) * chan_bytes
+    s1 = tm.get("eval_step1_ms", 0.0) / passes
+    if spec and s1 > 0:
+        return "k_eval_spec_step2+k_eval_spec_step1", [("k_eval_spec_step2", total - s1, b2), ("k_eval_spec_step1", s1, b1)]
+    name = "k_eval_spec" if spec else ("k_eval_haar" if feature_type == 0 else "k_eval_lbp")
+    return name, [(name, total, b1 + b2)]
+
+
 PROFILE_ROUND = "r04"  # profiles/<round>_traffic_k_eval*.json, profiles/<round>_pmc_eval*.json
 
 
@@ -169,7 +184,7 @@ def measure_extra_workload(cc, torch, dev, dev_index, cascade, specialize, frame
     from oracle import oracle as orc
     want = orc.detect_multiscale(orc.load_cascade_xml(cascade), frames_host[0], args.scale_factor, args.min_neighbors, nthreads=usable_cores())
     same = want.shape == last[0].shape and bool((want == last[0]).all())
-    kernel_name = "k_eval_spec" if spec else ("k_eval_haar" if inf["feature_type"] == 0 else "k_eval_lbp")
+    kernel_name, _ = cascade_kernel_launches(tm, spec, inf["feature_type"], plan, 8 if inf["feature_type"] == 0 else 4)
     full_hd = (W, H) == (1920, 1080) and abs(args.scale_factor - 1.1) < 1e-12 and args.content == "natural" and "uniform" not in label
     traffic, traffic_note, secondary = replay_counters("" if inf["feature_type"] == 0 else "_lbp", kernel_name, os.path.basename(cascade), fpl, full_hd)
     del clf
@@ -568,7 +583,7 @@ def main():
     frames_per_launch = tm["frames"] / max(tm["eval_launches"], 1)
     ach = eval_bytes_per_frame * frames_per_launch / (eval_ms * 1e-3) / 1e9 if eval_ms > 0 else 0.0
     src_sha = kernel_source_sha16()
-    kernel_name = "k_eval_spec" if spec_stages else ("k_eval_haar" if inf["feature_type"] == 0 else "k_eval_lbp")
+    kernel_name, kernel_launches = cascade_kernel_launches(tm, spec_stages, inf["feature_type"], plan, chan_bytes)
     full_hd = (W, H) == (1920, 1080) and abs(args.scale_factor - 1.1) < 1e-12
     lbp_suffix = "" if inf["feature_type"] == 0 else "_lbp"
     traffic, traffic_note, secondary = replay_counters(lbp_suffix, kernel_name, os.path.basename(args.cascade), frames_per_launch, full_hd)
@@ -622,6 +637,12 @@ def main():
         "host_frames": host_frames_leg,
         "roofline": {
             "kernel": kernel_name,
+            # one entry per cascade-kernel launch of a pass, named as a kernel trace names it (rocprofv3 --stats lists them
+            # separately: its averages are these): the object's own achieved / avg_launch_ms are the pass's, i.e. their sum
+            "kernels": [{"kernel": n, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": round(b * frames_per_launch),
+                         "achieved": round(b * frames_per_launch / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
+                         "frac": round(b * frames_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None}
+                        for n, ms, b in kernel_launches],
             "bound": "hbm",
             "achieved": round(ach, 2),
             "peak": HBM_PEAK_GBS,

@@ -57,7 +57,7 @@ class DetectorTimings(C.Structure):
     _fields_ = [("resize_ms", C.c_double), ("integral_ms", C.c_double), ("eval_ms", C.c_double), ("finalize_ms", C.c_double),
                 ("resize_launches", C.c_int64), ("integral_launches", C.c_int64), ("eval_launches", C.c_int64),
                 ("finalize_launches", C.c_int64), ("frames", C.c_int64), ("grid_windows", C.c_int64),
-                ("integral_elems", C.c_int64)]
+                ("integral_elems", C.c_int64), ("eval_step1_ms", C.c_double)]
 
 
 class Split(C.Structure):

@@ -2255,7 +2255,7 @@ static cc_status build_plan(cc_detector* d, int w, int h, const cc_detect_params
   return CC_OK;
 }
 
-enum { EV_RESIZE = 0, EV_INTEGRAL = 1, EV_EVAL = 2, EV_FILTER = 3 };
+enum { EV_RESIZE = 0, EV_INTEGRAL = 1, EV_EVAL = 2, EV_FILTER = 3, EV_EVAL_STEP1 = 4 };
 
 struct EvScope {  // records a pair of events around a group of launches when profiling is on
   cc_detector* d;
@@ -2263,7 +2263,7 @@ struct EvScope {  // records a pair of events around a group of launches when pr
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t st;
   EvScope(cc_detector* d_, int kind_, hipStream_t st_) : d(d_), kind(kind_), st(st_) {
-    if (!d->profiling) return;
+    if (!d->profiling || kind < 0) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
       a = b = nullptr;
       return;
@@ -2285,6 +2285,7 @@ static void collect_events(cc_detector* d) {
         case EV_RESIZE: d->tm.resize_ms += ms; d->tm.resize_launches++; break;
         case EV_INTEGRAL: d->tm.integral_ms += ms; d->tm.integral_launches++; break;
         case EV_EVAL: d->tm.eval_ms += ms; d->tm.eval_launches++; break;
+        case EV_EVAL_STEP1: d->tm.eval_step1_ms += ms; break;
         case EV_FILTER: d->tm.finalize_ms += ms; d->tm.finalize_launches++; break;
       }
     }
@@ -2455,6 +2456,8 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
       A.tiles = L.tiles;
       if (L.fn) {
         void* params[] = {&A};
+        // (the pass's EV_EVAL pair spans all cascade-kernel launches; the STEP-1 module's launch is also timed on its own)
+        EvScope ev1(d, i == 1 ? EV_EVAL_STEP1 : -1, st);
         CC_HIP(hipModuleLaunchKernel(L.fn, (unsigned)L.n_tiles, (unsigned)nf, 1, EVAL_THREADS, 1, 1, (unsigned)L.lds, st, params, nullptr));
       } else if (haar)
         hipLaunchKernelGGL(k_eval_haar, dim3(L.n_tiles, nf), dim3(EVAL_THREADS), L.lds, st, A);
@@ -3270,7 +3273,8 @@ static cc_status spec_install(cc_detector* d, const std::vector<SpecCode>& codes
     Loaded x;
     x.tile_y = c.tile_y;
     x.only_step = c.only_step;
-    if (hipModuleLoadData(&x.mod, c.code.data()) != hipSuccess || hipModuleGetFunction(&x.fn, x.mod, "k_eval_spec") != hipSuccess) {
+    const char* entry = c.only_step == 1 ? "k_eval_spec_step1" : c.only_step == 2 ? "k_eval_spec_step2" : "k_eval_spec";
+    if (hipModuleLoadData(&x.mod, c.code.data()) != hipSuccess || hipModuleGetFunction(&x.fn, x.mod, entry) != hipSuccess) {
       (void)hipGetLastError();
       if (x.mod) (void)hipModuleUnload(x.mod);
       unload_all();
@@ -3538,9 +3542,11 @@ cc_status cc_detector_create(const cc_cascade* c, int device, int max_batch, cc_
     // group keep executing; the gain is in the LATE stages, where a handful of windows per tile pay a barrier round per
     // stage. Hence two knobs: groups start at stage `from`, and hold up to `budget` stumps.
     const bool lbp = !haar && !trees;
-    // LBP with its wave phase (which takes over below 24 windows): groups of <= 20 stumps from stage 2 on 4.91-5.06,
-    // 12 from stage 1: 5.04-5.25, one stage per group 5.29, 30 from stage 2: 5.36
-    int budget = lbp ? 20 : 0, from = lbp ? 2 : 1;
+    // LBP with its wave phase (which takes over below 24 windows), round 3 (tiles of 8 rows, bank-class table): groups of
+    // <= 20 stumps from stage 2 on 4.91-5.06, 12 from stage 1: 5.04-5.25, one stage per group 5.29, 30 from stage 2: 5.36.
+    // Round 4 (list queue from stage 2; specialised kernel on tiles of 20 rows): <= 14 stumps 3.70, <= 20 3.87, <= 30 4.17;
+    // at 8 rows 4.84 / 4.87 / 5.13.
+    int budget = lbp ? 14 : 0, from = lbp ? 2 : 1;
     if (const char* e = std::getenv("CCAMD_GROUP_STUMPS")) budget = trees ? 0 : std::max(0, std::atoi(e));  // tuning
     if (const char* e = std::getenv("CCAMD_GROUP_FROM")) from = std::max(1, std::atoi(e));
     std::vector<int> gf;

@@ -237,6 +237,10 @@ typedef struct cc_detector_timings {
   int64_t frames;         /* frames processed */
   int64_t grid_windows;   /* grid windows evaluated */
   int64_t integral_elems; /* integral entries per channel produced */
+  /* eval_ms spans ALL cascade-kernel launches of a pass (eval_launches counts passes). A run-time specialised Haar kernel is
+   * one module per step (k_eval_spec_step2 over the tiles of STEP-2 scales, then k_eval_spec_step1): eval_step1_ms is the
+   * part of eval_ms the STEP-1 module's launches took (0 when the pass is a single launch). */
+  double eval_step1_ms;
 } cc_detector_timings;
 CC_API cc_status cc_detector_set_profiling(cc_detector* d, int enabled);
 CC_API cc_status cc_detector_get_timings(cc_detector* d, cc_detector_timings* t, int reset);

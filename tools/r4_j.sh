@@ -1,0 +1,5 @@
+#!/bin/bash
+# Round 4, run J: the whole GPU suite on the final kernels, then the committed evidence (tools/r4_final_profiles.sh).
+timeout -k 10 1100 python -m pytest tests -v -m gpu --timeout 300 > gpurun_out/r4_t5.log 2>&1
+tail -n 3 gpurun_out/r4_t5.log
+bash tools/r4_final_profiles.sh

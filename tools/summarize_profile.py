@@ -38,15 +38,21 @@ except Exception as e:  # noqa: BLE001
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_sha16  # noqa: E402
 summary["kernel_src_sha16"] = kernel_source_sha16()
-for k, v in summary["kernels"].items():
-    if k.startswith("k_eval") and "FETCH_SIZE_KB_per_launch_raw" in v and "WRITE_SIZE_KB_per_launch_raw" in v and "bench" in summary:
-        fpl = summary["bench"]["roofline"]["frames_per_launch"]
-        json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_bench.sh {tag}), MI355X, bench.py "
-                             "--cpu-frames 0 --steps 2 --warmup 1, CCAMD_NO_FRONT_OVERLAP=1 (counters are device-wide)",
-                   "kernel": k, "cascade": summary["bench"]["config"]["cascade"].split(" ")[0], "kernel_src_sha16": summary["kernel_src_sha16"],
-                   "frames_per_launch": fpl, "fetch_correction": 2.0,
-                   "fetch_size_kb_raw_per_launch": v["FETCH_SIZE_KB_per_launch_raw"], "write_size_kb_raw_per_launch": v["WRITE_SIZE_KB_per_launch_raw"],
-                   "hbm_bytes_per_frame": (2.0 * v["FETCH_SIZE_KB_per_launch_raw"] + v["WRITE_SIZE_KB_per_launch_raw"]) * 1024 / fpl},
-                  open(f"profiles/{dst_prefix.split('_')[0]}_traffic_k_eval{suffix}.json", "w"), indent=1)
+# a pass is one launch of every cascade-kernel module (a specialised Haar kernel: one per step): sum their per-launch averages
+ev = sorted([k for k, v in summary["kernels"].items() if k.startswith("k_eval") and "FETCH_SIZE_KB_per_launch_raw" in v and "WRITE_SIZE_KB_per_launch_raw" in v],
+            reverse=True)
+if ev and "bench" in summary:
+    fpl = summary["bench"]["roofline"]["frames_per_launch"]
+    fetch = sum(summary["kernels"][k]["FETCH_SIZE_KB_per_launch_raw"] for k in ev)
+    write = sum(summary["kernels"][k]["WRITE_SIZE_KB_per_launch_raw"] for k in ev)
+    json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_bench.sh {tag}), MI355X, bench.py "
+                         "--cpu-frames 0 --steps 2 --warmup 1, CCAMD_NO_FRONT_OVERLAP=1 (counters are device-wide); per pass = summed over the "
+                         "cascade kernel's modules",
+               "kernel": "+".join(ev), "cascade": summary["bench"]["config"]["cascade"].split(" ")[0], "kernel_src_sha16": summary["kernel_src_sha16"],
+               "frames_per_launch": fpl, "fetch_correction": 2.0,
+               "fetch_size_kb_raw_per_launch": fetch, "write_size_kb_raw_per_launch": write,
+               "per_kernel_kb_raw": {k: {"fetch": summary["kernels"][k]["FETCH_SIZE_KB_per_launch_raw"], "write": summary["kernels"][k]["WRITE_SIZE_KB_per_launch_raw"]} for k in ev},
+               "hbm_bytes_per_frame": (2.0 * fetch + write) * 1024 / fpl},
+              open(f"profiles/{dst_prefix.split('_')[0]}_traffic_k_eval{suffix}.json", "w"), indent=1)
 json.dump(summary, open(f"profiles/{dst_prefix}_summary.json", "w"), indent=1)
 print(json.dumps(summary["kernels"], indent=1))
