@@ -289,32 +289,47 @@ def setup_gather(args, rank, world, dev_index, comm_dev):
         tcp = os.environ.get("CCAMD_COMM_TRANSPORT") == "tcp"
         if (args.backend == "nccl" or tcp) and not os.environ.get("CCAMD_BENCH_TORCH_GATHER"):
             from cascadeclassifier_amd.distributed import Comm
+            # ncclCommInitRank / ncclAllGather with more than one rank have never run on hardware (no multi-GPU box so far): both
+            # steps run under a watchdog, so that a rank stuck inside them makes EVERY rank fall back to the torch collective
+            # (the verdict is an all_reduce over the ranks) instead of hanging the measurement.
+            limit = float(os.environ.get("CCAMD_BENCH_COMM_TIMEOUT_S", "90"))
+
+            def guarded(fn):
+                import threading
+                box = {}
+
+                def body():
+                    try:
+                        box["value"] = fn()
+                    except Exception as e:  # noqa: BLE001
+                        box["error"] = e
+                th = threading.Thread(target=body, daemon=True)
+                th.start()
+                th.join(limit)
+                if th.is_alive():
+                    return None, TimeoutError(f"no answer within {limit:.0f} s")
+                return box.get("value"), box.get("error")
             ok = torch.zeros(1, dtype=torch.int32, device=comm_dev)
-            try:
-                comm = Comm.from_torch(dev_index)
+            comm, err = guarded(lambda: Comm.from_torch(dev_index))
+            if err is None and comm is not None:
                 ok += 1
-            except Exception as e:  # noqa: BLE001
-                print(f"[bench] rank {rank}: cc_comm_create failed ({e}); gathering with torch.distributed", file=sys.stderr)
+            else:
+                print(f"[bench] rank {rank}: cc_comm_create failed ({err}); gathering with torch.distributed", file=sys.stderr)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks or none
             if int(ok.item()) == 1:
-                # one trial gather before anything is timed: the C ABI's collective has run on CPU transports and on one rank
-                # only (no multi-GPU box so far); if it fails on any rank, every rank falls back to the torch collective
+                # one trial gather before anything is timed; if it fails on any rank, every rank falls back to the torch collective
                 ok.fill_(0)
-                try:
-                    trial = gather_detections([np.array([[rank, 0, 1, 1]], np.int32)], device=comm_dev, comm=comm)
-                    if len(trial) == world and all(len(t) == 1 and int(t[0][0]) == r for r, t in enumerate(trial)):
-                        ok += 1
-                except Exception as e:  # noqa: BLE001
-                    print(f"[bench] rank {rank}: cc_gather_detections failed ({e}); gathering with torch.distributed", file=sys.stderr)
+                trial, err = guarded(lambda: gather_detections([np.array([[rank, 0, 1, 1]], np.int32)], device=comm_dev, comm=comm))
+                if err is None and trial is not None and len(trial) == world and all(len(t) == 1 and int(t[0][0]) == r for r, t in enumerate(trial)):
+                    ok += 1
+                else:
+                    print(f"[bench] rank {rank}: cc_gather_detections failed ({err}); gathering with torch.distributed", file=sys.stderr)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
                 gather_kind = "cc_gather_detections (C ABI, " + ("loopback TCP transport" if tcp else "RCCL ncclAllGather x2") + ")"
             else:
                 if comm is not None:
-                    try:
-                        comm.close()
-                    except Exception:  # noqa: BLE001
-                        pass
+                    guarded(comm.close)
                 comm = None
     return comm, gather_kind
 

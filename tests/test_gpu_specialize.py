@@ -364,3 +364,30 @@ def test_fast_variance_norm_factor_is_the_two_rounded_operations():
     assert bad.value == 0
     L.check(L.lib().cc_debug_vnf_check(0, 1 << 28, 7, C.byref(bad)))
     assert bad.value == 0
+
+
+@pytest.mark.parametrize("env", [
+    {"CCAMD_SPEC_ONE_MODULE": "1"},                                   # Haar: one module for both steps, 8 rows
+    {"CCAMD_SPEC_TILE_Y1": "8", "CCAMD_SPEC_TILE_Y2": "8"},           # two modules, library height
+    {"CCAMD_SPEC_TILE_Y1": "16", "CCAMD_SPEC_TILE_Y2": "12"},         # QUEUE_ROWS = 32 / 24 (not a power of two)
+    {"CCAMD_SPEC_TILE_Y": "20"},                                      # both modules 20 rows: five window rows per thread
+    {"CCAMD_SPEC_TWO_MODULES": "1", "CCAMD_SPEC_TILE_Y1": "12"},      # LBP: a module per step, 12 / 20 rows
+    {"CCAMD_SPEC_TILE_Y": "8"},                                       # LBP at the library's height (two rows per thread: spec_stage0_x2)
+    {"CCAMD_SPEC_TILE_Y": "32", "CCAMD_WAVE_BELOW": "64"},            # LBP: 2 048 windows per block, the widest wave phase
+])
+def test_tile_heights_and_modules_do_not_change_results(lbp_xml, haar_xml, env, monkeypatch):
+    """Round 4: the specialised kernel is compiled with its own tile height, as one module or one per step (spec_modules).
+    Whatever the split and the heights -- incl. heights whose queue-row count is not a power of two, the rolled dense loop of
+    tiles with more than two window rows per thread, and a second module for LBP -- every window's code, exit stage, stage
+    sum, visited flag and every rectangle equal the CPU oracle's; frames larger and smaller than a tile, both steps."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("CCAMD_CACHE_DIR", "")
+    img, img2 = frame_natural(640, 360, 31), frame_uniform(150, 100, 32)
+    for xml, k in ((lbp_xml, 20), (haar_xml, 4)):
+        o = orc.load_cascade_xml(xml)
+        p = cc.CascadeClassifier(xml)
+        assert p.specialize(k) == k
+        n = _same_as_oracle(p, o, img, 1.1)
+        n += _same_as_oracle(p, o, img2, 1.25)
+        assert n > 0
