@@ -106,6 +106,7 @@ struct cc_evaluator {
   EBuf<LbpFeatDev> d_lbp_plain;
   EBuf<uint8_t> d_pred;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  hipEvent_t ev_piece[8] = {};  // categorical split search: one per piece of the sums on its way back (cc_split.hip)
   double last_ms = 0;
   int S = 16;
   // resident tables of the split search (cc_eval_presort): per group of 64 features the sorted values and sample
@@ -114,6 +115,8 @@ struct cc_evaluator {
   EBuf<uint16_t> d_sorted_idx16;
   EBuf<int32_t> d_sorted_idx32;
   EBuf<uint8_t> d_codes;  // LBP: [feature][sample] codes
+  int cat_sorted_n = 0;          // samples per variable in d_cat_sorted (0: not built)
+  EBuf<uint32_t> d_cat_sorted;  // LBP: (sample << 8 | code) in (code, sample) order, [group][rank][64] (cc_split.hip)
   int presort_n = 0;      // samples covered by the tables (0 = none)
   int presort_f0 = 0, presort_f1 = 0;  // variables covered by the tables
   EBuf<double> d_split_tab, d_split_out;
@@ -137,6 +140,8 @@ struct cc_evaluator {
   ~cc_evaluator() {
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
+    for (hipEvent_t& ev : ev_piece)
+      if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };

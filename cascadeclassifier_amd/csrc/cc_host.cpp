@@ -273,13 +273,28 @@ void split_categories(const double* hist, int n_cat, bool is_classifier, bool gi
   out.quality = -1;
   out.n_left = 0;
   std::memset(out.subset, 0, sizeof(out.subset));
-  std::vector<int> order((size_t)n_cat);
-  std::vector<double> key((size_t)n_cat);
+  // scratch on the stack for the usual 256 categories (8 464 calls per node search: no allocator traffic)
+  constexpr int kStack = 256;
+  int order_s[kStack];
+  double key_s[kStack], tot_s[kStack], cnt_s[kStack];
+  std::vector<int> order_v;
+  std::vector<double> key_v, tot_v, cnt_v;
+  int* order = order_s;
+  double *key = key_s, *tot = tot_s, *cnt = cnt_s;
+  if (n_cat > kStack) {
+    order_v.resize((size_t)n_cat);
+    key_v.resize((size_t)n_cat);
+    tot_v.resize((size_t)n_cat);
+    cnt_v.resize((size_t)n_cat);
+    order = order_v.data();
+    key = key_v.data();
+    tot = tot_v.data();
+    cnt = cnt_v.data();
+  }
   for (int c = 0; c < n_cat; c++) order[(size_t)c] = c;
   double best = -1.0;  // init_quality of a search on its own
   int best_pos = -1;
   if (!is_classifier) {
-    std::vector<double> tot((size_t)n_cat), cnt((size_t)n_cat);
     double right_w = 0, right_s = 0;
     for (int c = 0; c < n_cat; c++) {
       const double s = hist[2 * c], w = hist[2 * c + 1];
@@ -288,7 +303,7 @@ void split_categories(const double* hist, int n_cat, bool is_classifier, bool gi
       cnt[(size_t)c] = w;
       key[(size_t)c] = std::fabs(w) > DBL_EPSILON ? s / w : 0;  // average response of the category
     }
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return key[(size_t)a] < key[(size_t)b]; });
+    std::sort(order, order + n_cat, [&](int a, int b) { return key[(size_t)a] < key[(size_t)b]; });
     for (int c = 0; c < n_cat; c++) tot[(size_t)c] = key[(size_t)c] * cnt[(size_t)c];  // "revert back to unnormalized sums"
     double left_w = 0, left_s = 0;
     for (int pos = 0; pos < n_cat - 1; pos++) {
@@ -316,7 +331,7 @@ void split_categories(const double* hist, int n_cat, bool is_classifier, bool gi
       key[(size_t)c] = hist[2 * c + 1];  // weight of the category's class-1 samples
     }
     double left_w = 0, right_w = rcw[0] + rcw[1];
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return key[(size_t)a] < key[(size_t)b]; });
+    std::sort(order, order + n_cat, [&](int a, int b) { return key[(size_t)a] < key[(size_t)b]; });
     for (int pos = 0; pos < n_cat - 1; pos++) {
       const int c = order[(size_t)pos];
       const double w0 = hist[2 * c], w1 = hist[2 * c + 1];

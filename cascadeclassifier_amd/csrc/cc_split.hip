@@ -16,6 +16,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -517,9 +518,173 @@ __global__ __launch_bounds__(256) void k_split_cat(const uint8_t* __restrict__ c
   hist[((size_t)f * 256 + cat) * 2 + 1] = a1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Categorical variables, round 4: the same per-category sums from a table sorted once per stage.
+// cc_eval_presort sorts every LBP variable's samples by (code, sample) -- the stable row sort the ordered variables use --
+// and stores (sample << 8 | code) as [group][rank][64]. A category's samples are then one contiguous run in increasing
+// sample order, so ONE thread per variable (lane = variable: coalesced 256-B reads per rank, as k_split_ord) adds each
+// category up in the reference's order (o_cvboostree.cpp:456-464, :283-288) PROVIDED the node lists its samples in increasing
+// order, which is what a trainer's nodes do (the root is 0..n-1 or the kept samples in order, children are stable
+// partitions of their parent); any other node order takes k_split_cat above. Samples outside the node add +0.0 (exact:
+// the sums start at +0 and x + 0.0 == x). Work per node: n_pre table entries per variable instead of n * 256 compares.
+// ------------------------------------------------------------------------------------------------
+struct SplitCatArgs {
+  const uint32_t* packed;
+  const SplitEntry* tab;
+  int n_pre, n_vars, n_groups;
+  int waves;     // wavefronts of a block that own a (group, part) (the others only help to copy the table)
+  int parts;     // a variable's ranks are cut into this many parts ...
+  int part_len;  // ... of this many ranks (a multiple of SPLIT_CAT_DEPTH * SPLIT_CAT_UNROLL)
+  double* hist;
+};
+constexpr int SPLIT_CAT_UNROLL = 16;  // ranks per chunk: four 16-byte loads per lane
+constexpr int SPLIT_CAT_DEPTH = 6;    // chunks whose loads are in flight (one wavefront per SIMD: latency is hidden by distance, not by occupancy)
+constexpr int SPLIT_CAT_PAD_RANKS = (SPLIT_CAT_DEPTH + 2) * SPLIT_CAT_UNROLL;  // zeroed ranks behind the table: read-ahead without bounds checks
+// Table layout: [group][rank / 4][64 lanes][4 ranks] -- a lane reads four consecutive ranks of its variable with one 16-byte
+// load, a wavefront 1 KB per load instruction. Per-sample table: a sample outside the node is stored as +0.0 (8-byte form:
+// response * w, or w with the class in the sign bit) or {0, 0} (16-byte form), so it takes no test at all.
+// Parts: 8 464 LBP variables are 133 groups -- one wavefront on every eighth SIMD. A variable's ranks can be cut into parts,
+// each walked by its own wavefront, without splitting a sum: the part in which a category's run STARTS owns it, walks on past
+// its nominal end until that run is over, and skips a run it found already under way at its first rank. (Helps when runs
+// are short; aligned positives give a variable one code for half the samples, and the walk past the end then costs what
+// the cut saved.)
+template <bool CLASSIFIER, int TAB>
+__global__ __launch_bounds__(256) void k_split_cat_sorted(SplitCatArgs A) {
+  extern __shared__ double l_tab[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar: rank tests below are wave-uniform
+  if (TAB != 0) {
+    const int words = A.n_pre * (TAB == 1 ? 2 : 1);
+    const double* src = reinterpret_cast<const double*>(A.tab);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) l_tab[i] = src[i];
+    __syncthreads();
+  }
+  const int unit = blockIdx.x * A.waves + wave;
+  const int group = unit / A.parts, part = unit - group * A.parts;
+  if (wave >= A.waves || group >= A.n_groups) return;
+  const int f = group * 64 + lane;
+  const bool live = f < A.n_vars;
+  const int n4 = (A.n_pre + 3) >> 2;
+  const uint4* p = reinterpret_cast<const uint4*>(A.packed) + (size_t)group * n4 * 64 + lane;
+  double* h = A.hist + (size_t)(live ? f : 0) * 512;
+  const int begin = part * A.part_len, end = min(A.n_pre, begin + A.part_len);
+  if (begin >= A.n_pre) return;
+  // cur: the code of the run the walk is in; own: this part sums that run
+  int cur = -1;
+  if (begin > 0) cur = (int)(A.packed[(((size_t)group * n4 + ((begin - 1) >> 2)) * 64 + lane) * 4 + ((begin - 1) & 3)] & 255u);
+  bool own = false;
+  double a0 = 0, a1 = 0;
+  constexpr int U = SPLIT_CAT_UNROLL, D = SPLIT_CAT_DEPTH;
+  uint4 buf[D][U / 4];
+  auto load = [&](int r0, uint4(&x)[U / 4]) {
+#pragma unroll
+    for (int k = 0; k < U / 4; k++) x[k] = p[(size_t)((r0 >> 2) + k) * 64];
+  };
+  auto process = [&](int r0, const uint4(&x4)[U / 4]) {
+    uint32_t x[U];
+#pragma unroll
+    for (int k = 0; k < U / 4; k++) {
+      x[4 * k] = x4[k].x;
+      x[4 * k + 1] = x4[k].y;
+      x[4 * k + 2] = x4[k].z;
+      x[4 * k + 3] = x4[k].w;
+    }
+    double w[U], t[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const unsigned g = x[k] >> 8;
+      if (TAB == 2) {
+        t[k] = l_tab[g];
+        w[k] = 0;
+      } else {
+        const SplitEntry e = TAB == 1 ? reinterpret_cast<const SplitEntry*>(l_tab)[g] : A.tab[g];
+        w[k] = e.w;
+        t[k] = e.t;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      if (r0 + k >= A.n_pre) break;  // wave-uniform
+      const int code = (int)(x[k] & 255u);
+      if (code != cur) {
+        if (own && live) {
+          h[2 * cur] = a0;
+          h[2 * cur + 1] = a1;
+        }
+        a0 = 0;
+        a1 = 0;
+        cur = code;
+        own = r0 + k < end;  // a run that starts behind the nominal end is the next part's
+      }
+      if (TAB == 2) {
+        if (CLASSIFIER) {  // entry = w, class 1 in the sign bit: max(x, +0) is w for class 0 and 0 for class 1
+          a0 += fmax(t[k], 0.0);
+          a1 += fmax(-t[k], 0.0);
+        } else {  // entry = response * w with response +-1
+          a0 += t[k];
+          a1 += fabs(t[k]);
+        }
+      } else if (CLASSIFIER) {
+        const bool c1 = t[k] != 0.0;
+        a0 += c1 ? 0.0 : w[k];
+        a1 += c1 ? w[k] : 0.0;
+      } else {
+        a0 += t[k];
+        a1 += w[k];
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < D; d++) load(begin + d * U, buf[d]);
+  int r0 = begin;
+  while (r0 < end || (r0 < A.n_pre && __any(own))) {  // ... || runs that straddle the nominal end
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      process(r0 + d * U, buf[d]);
+      load(r0 + (D + d) * U, buf[d]);
+    }
+    r0 += D * U;
+  }
+  if (own && live) {
+    h[2 * cur] = a0;
+    h[2 * cur + 1] = a1;
+  }
+}
+
+// [rows][n] sorted codes (as floats) and sample positions -> (sample << 8 | code) as [group][rank / 4][64][4]
+__global__ __launch_bounds__(256) void k_interleave_cat(const float* __restrict__ vals, const int* __restrict__ idx, int rows, int n,
+                                                        uint32_t* __restrict__ out, size_t group0) {
+  __shared__ uint32_t tv[64][65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 64, g = blockIdx.y;
+  for (int j = wave; j < 64; j += 4) {
+    const int row = g * 64 + j;
+    uint32_t v = 0;
+    if (row < rows && r0 + lane < n) v = ((uint32_t)idx[(size_t)row * n + r0 + lane] << 8) | ((uint32_t)(int)vals[(size_t)row * n + r0 + lane] & 255u);
+    tv[j][lane] = v;
+  }
+  __syncthreads();
+  const size_t n4 = ((size_t)n + 3) >> 2;
+  for (int rr = wave; rr < 64; rr += 4) {  // [group][rank / 4][lane][rank % 4]; r0 is a multiple of 64
+    if (r0 + rr >= n) break;
+    out[(((group0 + g) * n4 + ((r0 + rr) >> 2)) * 64 + lane) * 4 + (rr & 3)] = tv[lane][rr];
+  }
+}
+
 }  // namespace ccamd
 
 using namespace ccamd;
+
+// compute units of a device (hipGetDeviceProperties fills a 1.5 KB struct and takes ~1 ms: asked once per device)
+static int device_cus(int device) {
+  static std::mutex mu;
+  static int cached[64] = {0};
+  std::lock_guard<std::mutex> lk(mu);
+  if (device >= 0 && device < 64 && cached[device] > 0) return cached[device];
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v < 1) v = 256;
+  if (device >= 0 && device < 64) cached[device] = v;
+  return v;
+}
 
 extern "C" {
 
@@ -543,28 +708,83 @@ cc_status cc_eval_presort_range(cc_evaluator* e, int fi_begin, int fi_end, int n
   const size_t groups = ((size_t)F + 63) / 64;
   size_t free_b = 0, total_b = 0;
   CC_HIP(hipMemGetInfo(&free_b, &total_b));
-  const size_t resident = haar ? groups * 64 * (size_t)N * (4 + (N <= 65536 ? 2 : 4)) : (size_t)F * N;
-  const size_t have = e->d_sorted_val.n * 4 + e->d_sorted_idx16.n * 2 + e->d_sorted_idx32.n * 4 + e->d_codes.n + e->d_out.n * 4;
-  const size_t scratch = (size_t)FB * N * (haar ? 16 : 4);
+  // LBP keeps the (code, sample)-sorted table of k_split_cat_sorted beside the codes while sample numbers fit 24 bits
+  const bool no_cat_table = std::getenv("CCAMD_SPLIT_CAT_STREAM") != nullptr;  // A/B: round-1 categorical search only
+  const bool cat_table = !haar && N < (1 << 24) && !no_cat_table;
+  const size_t resident = haar ? groups * 64 * (size_t)N * (4 + (N <= 65536 ? 2 : 4)) : (size_t)F * N + (cat_table ? groups * 64 * ((size_t)N + 3 + SPLIT_CAT_PAD_RANKS) * 4 : 0);
+  const size_t have = e->d_sorted_val.n * 4 + e->d_sorted_idx16.n * 2 + e->d_sorted_idx32.n * 4 + e->d_codes.n + e->d_cat_sorted.n * 4 + e->d_out.n * 4;
+  const size_t scratch = (size_t)FB * N * (haar || cat_table ? 16 : 4);
   if (resident + scratch > free_b + have)
     return set_error(CC_ERR_UNSUPPORTED, "cc_eval_presort: needs %.1f GB of device memory (%.1f GB free)",
                      (double)(resident + scratch) / 1e9, (double)(free_b + have) / 1e9);
+  EBuf<float> keys_out;
+  EBuf<int> iota, sorted, offsets;
+  EBuf<char> temp;
+  const size_t cap = (size_t)FB * N;
+  if (haar || cat_table) {
+    CC_HIP(e->d_out.ensure(cap));
+    CC_HIP(keys_out.ensure(cap));
+    CC_HIP(sorted.ensure(cap));
+  }
+  bool scratch_for_device_sort = false;
+  // stable sort of the nf rows of d_out (one variable per row) into keys_out / sorted
+  auto sort_rows = [&](int nf) -> cc_status {
+    if (N <= sort_rows_block_limit()) {  // a row fits one block: sorted in LDS, read once and written once
+      // a part that refuses the ~100 KB LDS request (or the launch) takes the device-wide sort below instead of failing
+      if (sort_rows_block(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream) == hipSuccess) return CC_OK;
+      (void)hipGetLastError();
+    }
+    if (!scratch_for_device_sort) {
+      CC_HIP(iota.ensure(cap));
+      CC_HIP(offsets.ensure((size_t)FB + 1));
+      std::vector<int> off((size_t)FB + 1);
+      for (int i = 0; i <= FB; i++) off[(size_t)i] = (int)((size_t)i * N);
+      CC_HIP(hipMemcpyAsync(offsets.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, e->stream));
+      CC_HIP(hipStreamSynchronize(e->stream));  // `off` is pageable and about to go out of scope
+      hipLaunchKernelGGL(k_iota_rows2, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, e->stream, iota.p, cap, N);
+      scratch_for_device_sort = true;
+    }
+    const size_t total = (size_t)nf * N;
+    size_t temp_bytes = 0;
+    CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf, offsets.p,
+                                                       offsets.p + 1, 0, 32, e->stream));
+    CC_HIP(temp.ensure(std::max<size_t>(temp_bytes, 1)));
+    // stable: equal values keep increasing sample order
+    CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(temp.p, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf, offsets.p,
+                                                       offsets.p + 1, 0, 32, e->stream));
+    return CC_OK;
+  };
   if (!haar) {
     CC_HIP(e->d_codes.ensure((size_t)F * N));
+    if (cat_table) {
+      // ranks padded to a multiple of 4 per group (the tail of a group's last quad is never summed: r >= n_pre); zeroed
+      // padding behind the last group for the read-ahead
+      const size_t used = groups * 64 * ((((size_t)N + 3) >> 2) << 2), pad = (size_t)SPLIT_CAT_PAD_RANKS * 64;
+      CC_HIP(e->d_cat_sorted.ensure(used + pad));
+      CC_HIP(hipMemsetAsync(e->d_cat_sorted.p, 0, (used + pad) * sizeof(uint32_t), e->stream));
+    }
+    e->cat_sorted_n = 0;
     for (int f0 = 0; f0 < F; f0 += FB) {
-      const int f1 = std::min(F, f0 + FB);
-      const size_t total = (size_t)(f1 - f0) * N;
+      const int f1 = std::min(F, f0 + FB), nf = f1 - f0;
+      const size_t total = (size_t)nf * N;
       CC_HIP(e->d_out.ensure(total));
       st = launch_batch(e, false, feats, fi_begin + f0, fi_begin + f1, nullptr, N, e->d_out.p, 1, 0);
       if (st != CC_OK) return st;
       hipLaunchKernelGGL(k_codes_u8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, e->d_out.p,
                          e->d_codes.p + (size_t)f0 * N, total);
+      if (cat_table) {
+        st = sort_rows(nf);
+        if (st != CC_OK) return st;
+        hipLaunchKernelGGL(k_interleave_cat, dim3((unsigned)((N + 63) / 64), (unsigned)((nf + 63) / 64)), dim3(256), 0, e->stream, keys_out.p,
+                           sorted.p, nf, N, e->d_cat_sorted.p, (size_t)f0 / 64);
+      }
     }
     CC_HIP(hipGetLastError());
     CC_HIP(hipStreamSynchronize(e->stream));
     e->presort_n = N;
     e->presort_f0 = fi_begin;
     e->presort_f1 = fi_end;
+    e->cat_sorted_n = cat_table ? N : 0;
     return CC_OK;
   }
   const bool idx16 = N <= 65536;
@@ -580,41 +800,12 @@ cc_status cc_eval_presort_range(cc_evaluator* e, int fi_begin, int fi_end, int n
       CC_HIP(hipMemsetAsync(e->d_sorted_idx32.p + used, 0, pad * sizeof(int32_t), e->stream));
     }
   }
-  EBuf<float> keys_out;
-  EBuf<int> iota, sorted, offsets;
-  EBuf<char> temp;
-  const size_t cap = (size_t)FB * N;
-  CC_HIP(e->d_out.ensure(cap));
-  CC_HIP(keys_out.ensure(cap));
-  CC_HIP(iota.ensure(cap));
-  CC_HIP(sorted.ensure(cap));
-  CC_HIP(offsets.ensure((size_t)FB + 1));
-  std::vector<int> off((size_t)FB + 1);
-  for (int i = 0; i <= FB; i++) off[(size_t)i] = (int)((size_t)i * N);
-  CC_HIP(hipMemcpyAsync(offsets.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, e->stream));
-  hipLaunchKernelGGL(k_iota_rows2, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, e->stream, iota.p, cap, N);
   for (int f0 = 0; f0 < F; f0 += FB) {
     const int f1 = std::min(F, f0 + FB), nf = f1 - f0;
-    const size_t total = (size_t)nf * N;
     st = launch_batch(e, true, feats, fi_begin + f0, fi_begin + f1, nullptr, N, e->d_out.p, 1, 0);
     if (st != CC_OK) return st;
-    bool sorted_in_blocks = false;
-    if (N <= sort_rows_block_limit()) {  // a row fits one block: sorted in LDS, read once and written once
-      // a part that refuses the ~100 KB LDS request (or the launch) takes the device-wide sort below instead of failing
-      if (sort_rows_block(e->d_out.p, nf, N, keys_out.p, sorted.p, e->stream) == hipSuccess)
-        sorted_in_blocks = true;
-      else
-        (void)hipGetLastError();
-    }
-    if (!sorted_in_blocks) {
-      size_t temp_bytes = 0;
-      CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
-                                                         offsets.p, offsets.p + 1, 0, 32, e->stream));
-      CC_HIP(temp.ensure(std::max<size_t>(temp_bytes, 1)));
-      // stable: equal values keep increasing sample order
-      CC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(temp.p, temp_bytes, e->d_out.p, keys_out.p, iota.p, sorted.p, (int)total, nf,
-                                                         offsets.p, offsets.p + 1, 0, 32, e->stream));
-    }
+    st = sort_rows(nf);
+    if (st != CC_OK) return st;
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((nf + 63) / 64));
     if (idx16)
       hipLaunchKernelGGL((k_interleave<uint16_t>), grid, dim3(256), 0, e->stream, keys_out.p, sorted.p, nf, N, e->d_sorted_val.p,
@@ -735,9 +926,7 @@ cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, in
     static const bool lean = std::getenv("CCAMD_SPLIT_BRANCHY") == nullptr;
     int wpb = 1;
     if (tab_kind != 0) {
-      hipDeviceProp_t prop;
-      CC_HIP(hipGetDeviceProperties(&prop, e->device));
-      const int cus = std::max(1, prop.multiProcessorCount);
+      const int cus = device_cus(e->device);
       wpb = (int)std::min<size_t>(16, std::max<size_t>(1, (groups + cus - 1) / cus));
       if (const char* v = std::getenv("CCAMD_SPLIT_WAVES")) wpb = std::max(1, std::min(16, std::atoi(v)));
       if (tab_kind == 2 && lean && mode != 2) wpb = std::min(wpb, SPLIT_LEAN_WAVES);
@@ -821,52 +1010,153 @@ cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, in
     return CC_OK;
   }
   // ---- categorical (LBP) ----
-  CC_HIP(pin_in.ensure((size_t)n * (sizeof(SplitEntry) + 4)));
-  SplitEntry* tab = static_cast<SplitEntry*>(pin_in.p);
-  int32_t* idx_host = reinterpret_cast<int32_t*>(tab + n);
-  {
-    std::vector<uint8_t> seen((size_t)N, 0);
-    for (int i = 0; i < n; i++) {
-      const int g = sample_idx ? sample_idx[i] : i;
-      if (g < 0 || g >= N) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_find_best_split: sample index %d outside the %d presorted samples", g, N);
-      if (seen[(size_t)g]) return set_error(CC_ERR_INVALID_ARG, "cc_eval_find_best_split: sample %d occurs twice in the node", g);
-      seen[(size_t)g] = 1;
-      idx_host[i] = g;
-      tab[i].w = weights[i];
-      tab[i].t = is_classifier ? (double)class_labels[i] : responses[i] * weights[i];
-    }
-  }
-  CC_HIP(e->d_split_tab.ensure((size_t)n * 2));
-  CC_HIP(e->d_split_idx.ensure((size_t)n));
   const size_t hist_n = (size_t)F * 256 * 2;
   CC_HIP(e->d_split_out.ensure(hist_n));
-  CC_HIP(hipMemcpyAsync(e->d_split_tab.p, tab, (size_t)n * sizeof(SplitEntry), hipMemcpyHostToDevice, e->stream));
-  CC_HIP(hipMemcpyAsync(e->d_split_idx.p, idx_host, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
-  (void)hipEventRecord(e->ev_a, e->stream);
-  if (is_classifier)
-    hipLaunchKernelGGL(k_split_cat<true>, dim3((unsigned)F), dim3(256), 0, e->stream, e->d_codes.p, N, sample_idx ? e->d_split_idx.p : nullptr,
-                       reinterpret_cast<const SplitEntry*>(e->d_split_tab.p), n, e->d_split_out.p);
-  else
-    hipLaunchKernelGGL(k_split_cat<false>, dim3((unsigned)F), dim3(256), 0, e->stream, e->d_codes.p, N, sample_idx ? e->d_split_idx.p : nullptr,
-                       reinterpret_cast<const SplitEntry*>(e->d_split_tab.p), n, e->d_split_out.p);
-  (void)hipEventRecord(e->ev_b, e->stream);
-  CC_HIP(hipGetLastError());
+  bool ascending = true;  // the node lists its samples in increasing order: what k_split_cat_sorted's exactness needs
+  for (int i = 1; i < n && ascending && sample_idx; i++) ascending = sample_idx[i - 1] < sample_idx[i];
+  const bool stream_only = std::getenv("CCAMD_SPLIT_CAT_STREAM") != nullptr;  // read per call: tests compare the two paths
+  if (ascending && e->cat_sorted_n == N && !stream_only) {
+    bool unit_responses = !is_classifier;
+    if (!is_classifier)
+      for (int i = 0; i < n && unit_responses; i++) unit_responses = responses[i] == 1.0f || responses[i] == -1.0f;
+    const size_t lds_cap = 160 * 1024;
+    int tab_kind = 0;  // as for the ordered search: 2 = 8-byte entries in LDS, 1 = 16-byte entries in LDS, 0 = global memory
+    if ((is_classifier || unit_responses) && (size_t)N * 8 <= lds_cap)
+      tab_kind = 2;
+    else if ((size_t)N * 16 <= lds_cap)
+      tab_kind = 1;
+    if (std::getenv("CCAMD_SPLIT_GLOBAL_TABLE")) tab_kind = 0;
+    const size_t entry_bytes = tab_kind == 2 ? 8 : 16;
+    CC_HIP(pin_in.ensure((size_t)N * entry_bytes));
+    SplitEntry* tab16 = static_cast<SplitEntry*>(pin_in.p);
+    double* tab8 = static_cast<double*>(pin_in.p);
+    std::memset(pin_in.p, 0, (size_t)N * entry_bytes);  // not in the node: +0.0 / {0, 0}, adds nothing to any sum
+    for (int i = 0; i < n; i++) {  // strictly increasing: no sample twice
+      const int g = sample_idx ? sample_idx[i] : i;
+      if (g < 0 || g >= N) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_find_best_split: sample index %d outside the %d presorted samples", g, N);
+      const double w = weights[i];
+      if (tab_kind == 2)
+        tab8[g] = is_classifier ? (class_labels[i] ? -w : w) : responses[i] * w;
+      else {
+        tab16[g].w = w;
+        tab16[g].t = is_classifier ? (double)class_labels[i] : responses[i] * w;
+      }
+    }
+    CC_HIP(e->d_split_tab.ensure((size_t)N * 2));
+    CC_HIP(hipMemcpyAsync(e->d_split_tab.p, pin_in.p, (size_t)N * entry_bytes, hipMemcpyHostToDevice, e->stream));
+    (void)hipEventRecord(e->ev_a, e->stream);
+    CC_HIP(hipMemsetAsync(e->d_split_out.p, 0, hist_n * 8, e->stream));  // categories without a sample
+    const size_t groups = ((size_t)F + 63) / 64;
+    SplitCatArgs A;
+    A.packed = e->d_cat_sorted.p;
+    A.tab = reinterpret_cast<const SplitEntry*>(e->d_split_tab.p);
+    A.n_pre = N;
+    A.n_vars = F;
+    A.n_groups = (int)groups;
+    A.hist = e->d_split_out.p;
+    // One wavefront per (group, part); with the table in LDS a block owns a CU (<= 4 wavefronts of it): as many parts as
+    // give every CU a full block, no part shorter than 1 024 ranks. CCAMD_SPLIT_CAT_PARTS overrides (1 = round-4 first form).
+    const int cus = device_cus(e->device);
+    int parts = (int)std::max<size_t>(1, (size_t)cus * 4 / groups);
+    parts = std::max(1, std::min(parts, N / 1024));
+    if (const char* v = std::getenv("CCAMD_SPLIT_CAT_PARTS")) parts = std::max(1, std::min(64, std::atoi(v)));
+    const int chunk = SPLIT_CAT_DEPTH * SPLIT_CAT_UNROLL;
+    A.parts = parts;
+    A.part_len = ((N + parts - 1) / parts + chunk - 1) / chunk * chunk;
+    const size_t units = groups * (size_t)parts;
+    A.waves = tab_kind == 0 ? 4 : (int)std::min<size_t>(4, std::max<size_t>(1, (units + cus - 1) / cus));
+    const unsigned blocks = (unsigned)((units + A.waves - 1) / A.waves);
+    const size_t lds = tab_kind == 0 ? 0 : (size_t)N * entry_bytes;
+#define CC_LAUNCH_CAT(C, T)                                                                                                          \
+  do {                                                                                                                               \
+    if (lds > 64 * 1024)                                                                                                             \
+      CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_split_cat_sorted<C, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_split_cat_sorted<C, T>), dim3(blocks), dim3(256), lds, e->stream, A);                                      \
+  } while (0)
+    if (is_classifier) {
+      if (tab_kind == 2)
+        CC_LAUNCH_CAT(true, 2);
+      else if (tab_kind == 1)
+        CC_LAUNCH_CAT(true, 1);
+      else
+        CC_LAUNCH_CAT(true, 0);
+    } else {
+      if (tab_kind == 2)
+        CC_LAUNCH_CAT(false, 2);
+      else if (tab_kind == 1)
+        CC_LAUNCH_CAT(false, 1);
+      else
+        CC_LAUNCH_CAT(false, 0);
+    }
+#undef CC_LAUNCH_CAT
+    (void)hipEventRecord(e->ev_b, e->stream);
+    CC_HIP(hipGetLastError());
+  } else {
+    CC_HIP(pin_in.ensure((size_t)n * (sizeof(SplitEntry) + 4)));
+    SplitEntry* tab = static_cast<SplitEntry*>(pin_in.p);
+    int32_t* idx_host = reinterpret_cast<int32_t*>(tab + n);
+    {
+      std::vector<uint8_t> seen((size_t)N, 0);
+      for (int i = 0; i < n; i++) {
+        const int g = sample_idx ? sample_idx[i] : i;
+        if (g < 0 || g >= N) return set_error(CC_ERR_OUT_OF_RANGE, "cc_eval_find_best_split: sample index %d outside the %d presorted samples", g, N);
+        if (seen[(size_t)g]) return set_error(CC_ERR_INVALID_ARG, "cc_eval_find_best_split: sample %d occurs twice in the node", g);
+        seen[(size_t)g] = 1;
+        idx_host[i] = g;
+        tab[i].w = weights[i];
+        tab[i].t = is_classifier ? (double)class_labels[i] : responses[i] * weights[i];
+      }
+    }
+    CC_HIP(e->d_split_tab.ensure((size_t)n * 2));
+    CC_HIP(e->d_split_idx.ensure((size_t)n));
+    CC_HIP(hipMemcpyAsync(e->d_split_tab.p, tab, (size_t)n * sizeof(SplitEntry), hipMemcpyHostToDevice, e->stream));
+    CC_HIP(hipMemcpyAsync(e->d_split_idx.p, idx_host, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+    (void)hipEventRecord(e->ev_a, e->stream);
+    if (is_classifier)
+      hipLaunchKernelGGL(k_split_cat<true>, dim3((unsigned)F), dim3(256), 0, e->stream, e->d_codes.p, N, sample_idx ? e->d_split_idx.p : nullptr,
+                         reinterpret_cast<const SplitEntry*>(e->d_split_tab.p), n, e->d_split_out.p);
+    else
+      hipLaunchKernelGGL(k_split_cat<false>, dim3((unsigned)F), dim3(256), 0, e->stream, e->d_codes.p, N, sample_idx ? e->d_split_idx.p : nullptr,
+                         reinterpret_cast<const SplitEntry*>(e->d_split_tab.p), n, e->d_split_out.p);
+    (void)hipEventRecord(e->ev_b, e->stream);
+    CC_HIP(hipGetLastError());
+  }
+  // The 34.7 MB of sums (8 464 variables) come back in pieces; the host's part -- ordering each variable's categories and
+  // scanning them (split_categories) -- starts on a piece as soon as it has landed, on up to 16 threads.
   CC_HIP(pin_out.ensure(hist_n * 8));
-  CC_HIP(hipMemcpyAsync(pin_out.p, e->d_split_out.p, hist_n * 8, hipMemcpyDeviceToHost, e->stream));
-  CC_HIP(hipStreamSynchronize(e->stream));
-  float ms = 0;
-  if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_ms = ms;
-  const double* hist = static_cast<const double*>(pin_out.p);
+  constexpr int kPieces = 8;
+  for (int c = 0; c < kPieces; c++)
+    if (!e->ev_piece[c]) CC_HIP(hipEventCreateWithFlags(&e->ev_piece[c], hipEventDisableTiming));
+  const int per_piece = (F + kPieces - 1) / kPieces;
+  double* hist = static_cast<double*>(pin_out.p);
+  for (int c = 0; c < kPieces; c++) {
+    const int f0 = std::min(F, c * per_piece), f1 = std::min(F, f0 + per_piece);
+    if (f1 > f0)
+      CC_HIP(hipMemcpyAsync(hist + (size_t)f0 * 512, e->d_split_out.p + (size_t)f0 * 512, (size_t)(f1 - f0) * 512 * 8, hipMemcpyDeviceToHost, e->stream));
+    CC_HIP(hipEventRecord(e->ev_piece[c], e->stream));
+  }
   std::vector<CatSplit> res((size_t)F);
+  std::atomic<int> copy_failed{0};
   {
     const int nt = std::max(1, std::min<int>({(int)std::thread::hardware_concurrency(), 16, F / 64 + 1}));
     std::vector<std::thread> th;
     for (int t = 0; t < nt; t++)
       th.emplace_back([&, t]() {
-        for (int f = t; f < F; f += nt) split_categories(hist + (size_t)f * 512, 256, is_classifier, gini, res[(size_t)f]);
+        for (int c = 0; c < kPieces; c++) {
+          if (hipEventSynchronize(e->ev_piece[c]) != hipSuccess) {
+            copy_failed = 1;
+            return;
+          }
+          const int f0 = std::min(F, c * per_piece), f1 = std::min(F, f0 + per_piece);
+          for (int f = f0 + t; f < f1; f += nt) split_categories(hist + (size_t)f * 512, 256, is_classifier, gini, res[(size_t)f]);
+        }
       });
     for (auto& x : th) x.join();
   }
+  CC_HIP(hipStreamSynchronize(e->stream));
+  if (copy_failed) return set_error(CC_ERR_HIP, "cc_eval_find_best_split: copying the category sums back failed");
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_ms = ms;
   float best_q = -1.f;
   int winner = -1;
   for (int f = 0; f < F; f++) {

@@ -160,6 +160,38 @@ def test_lbp_root_and_subset(boost_type, criteria):
     _check(e, ev.LBP, 0, WIN, ints, labels, boost_type=boost_type, criteria=criteria, sample_idx=sub, seed=7)
 
 
+def test_lbp_nodes_in_increasing_order_use_the_sorted_table(monkeypatch):
+    """A node that lists its samples in increasing order (every node of a trainer) is searched from the (code, sample)-sorted
+    table (k_split_cat_sorted), any other order by streaming the codes (k_split_cat): both must equal the oracle, and each
+    other bit for bit, with the per-sample table in LDS (8- and 16-byte entries) and in global memory."""
+    e, imgs, labels, ints = _setup(ev.LBP, 0, WIN, 900, 21, dup=70)
+    rng = np.random.default_rng(8)
+    sub = np.sort(rng.choice(900, 411, replace=False))
+    for bt in (ev.BOOST_GENTLE, ev.BOOST_LOGIT, ev.BOOST_REAL, ev.BOOST_DISCRETE):
+        _check(e, ev.LBP, 0, WIN, ints, labels, boost_type=bt, sample_idx=sub, seed=9, real_responses=bt == ev.BOOST_LOGIT)
+        _check(e, ev.LBP, 0, WIN, ints, labels, boost_type=bt, sample_idx=sub[:2], seed=9)
+    lab = labels[sub].astype(np.int32)
+    w = _weights(len(sub), lab, 10, False)
+    resp = (lab * 2 - 1).astype(np.float32)
+    nv = _node_value(w, resp)
+    ref = e.find_best_split(w, sample_idx=sub.astype(np.int32), node_value=nv, boost_type=ev.BOOST_GENTLE, responses=resp, per_var=True)
+    monkeypatch.setenv("CCAMD_SPLIT_GLOBAL_TABLE", "1")
+    glob = e.find_best_split(w, sample_idx=sub.astype(np.int32), node_value=nv, boost_type=ev.BOOST_GENTLE, responses=resp, per_var=True)
+    monkeypatch.delenv("CCAMD_SPLIT_GLOBAL_TABLE")
+    # a variable's ranks cut into parts (what 20 000 samples get by default): a category belongs to the part its run starts in
+    for parts in (2, 5, 28):
+        monkeypatch.setenv("CCAMD_SPLIT_CAT_PARTS", str(parts))
+        for bt in (ev.BOOST_GENTLE, ev.BOOST_REAL):
+            _check(e, ev.LBP, 0, WIN, ints, labels, boost_type=bt, sample_idx=sub, seed=11)
+            _check(e, ev.LBP, 0, WIN, ints, labels, boost_type=bt, seed=12)
+    monkeypatch.delenv("CCAMD_SPLIT_CAT_PARTS")
+    monkeypatch.setenv("CCAMD_SPLIT_CAT_STREAM", "1")
+    stream = e.find_best_split(w, sample_idx=sub.astype(np.int32), node_value=nv, boost_type=ev.BOOST_GENTLE, responses=resp, per_var=True)
+    for other in (glob, stream):
+        assert all(np.array_equal(other[0][k], ref[0][k]) for k in ref[0])
+        assert (other[1].view(np.uint64) == ref[1].view(np.uint64)).all() and (other[2] == ref[2]).all()
+
+
 def test_equal_weights_first_round():
     """Round 0 of boosting: all positives share one weight and all negatives another, so many categories / prefixes tie
     exactly — the case where the reference's own tie handling (std::sort of categories, first-best-wins) decides."""
