@@ -2591,12 +2591,12 @@ static void retire_foreign(cc_detector* d) {
 // shape hands over, tools/detection/Cpp/main.cpp:27-45) cannot be copied asynchronously: the runtime stages it through
 // its own pinned chunks on the calling thread, copy after copy, and the call returns when the last one is on the device
 // (round 3: a step of 64 Full-HD frames took 19.9 ms this way against 17.2 with resident frames). So the detector keeps
-// its own pinned staging area, double-buffered like the device one: the frames of a pass are copied into it by a few host
+// its own pinned staging area, kStageSlots slots like the device one: the frames of a pass are copied into it by a few host
 // threads (tight rows), then ONE asynchronous copy on the front stream moves the pass to the device while the cascade
-// kernels of the pass before run -- and the caller's frames are free again when the call returns. The pinned slot is
-// reused two passes later; by then its pass has been retired (run_batch retires pass i when pass i + 1 is launched), so
-// its copy is long complete. Frames that already live in pinned memory (hipHostMalloc / hipHostRegister) skip the
-// staging copy.
+// kernels of the pass before run -- and the caller's frames are free again when the call returns. A pinned slot is
+// reused kStageSlots passes later; run_batch has retired its pass by then (it stages pass i + 1 only after pass i - 2 is
+// retired), so its copy is long complete. Frames that already live in pinned memory (hipHostMalloc / hipHostRegister)
+// skip the staging copy: those must stay valid until the call that retires their pass (include/cascadeclassifier_amd.h).
 static cc_status stage_host_frames(cc_detector* d, const uint8_t* src, int nf, int width, int height, size_t row_stride,
                                    size_t frame_stride, uint8_t* dev, size_t rs, size_t fs, int slot, hipStream_t front) {
   hipPointerAttribute_t attr;
