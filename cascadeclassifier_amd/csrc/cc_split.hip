@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1137,6 +1138,9 @@ cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, in
   }
   std::vector<CatSplit> res((size_t)F);
   std::atomic<int> copy_failed{0};
+  const bool trace = std::getenv("CCAMD_TRACE_SPLIT") != nullptr;  // host-side timeline of the call's tail (stderr)
+  const auto t_enq = std::chrono::steady_clock::now();
+  double landed_ms[kPieces] = {};
   {
     const int nt = std::max(1, std::min<int>({(int)std::thread::hardware_concurrency(), 16, F / 64 + 1}));
     std::vector<std::thread> th;
@@ -1147,11 +1151,17 @@ cc_status cc_eval_find_best_split(cc_evaluator* e, const int32_t* sample_idx, in
             copy_failed = 1;
             return;
           }
+          if (trace && t == 0) landed_ms[c] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count();
           const int f0 = std::min(F, c * per_piece), f1 = std::min(F, f0 + per_piece);
           for (int f = f0 + t; f < f1; f += nt) split_categories(hist + (size_t)f * 512, 256, is_classifier, gini, res[(size_t)f]);
         }
       });
     for (auto& x : th) x.join();
+  }
+  if (trace) {
+    std::fprintf(stderr, "[ccamd split] after the last enqueue: pieces landed (as seen by worker 0) at");
+    for (int c = 0; c < kPieces; c++) std::fprintf(stderr, " %.2f", landed_ms[c]);
+    std::fprintf(stderr, " ms; workers done at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
   }
   CC_HIP(hipStreamSynchronize(e->stream));
   if (copy_failed) return set_error(CC_ERR_HIP, "cc_eval_find_best_split: copying the category sums back failed");
