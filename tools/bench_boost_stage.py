@@ -5,7 +5,7 @@ data-parallel step on the device: batched setImage, presort of all variables (on
 split search and one feature row for the sample directions. The boosting bookkeeping between those calls (node values,
 w *= exp(-y f), renormalisation; boost.cpp:378-398, o_cvboostree.cpp:657-732) is the reference's serial host code,
 restated here in numpy with sequential double sums. Prints one JSON line.
-usage: bench_boost_stage.py [rounds=16] [n_samples=20000] [easy|hard]
+usage: bench_boost_stage.py [rounds=16] [n_samples=20000] [easy|hard] [HAAR|LBP]
   easy = SURVEY config 5 as specified (template + N(0,15^2) vs uniform noise: one stump separates it);
   hard = positives template + N(0,40^2), negatives a half-and-half blend with a second template + N(0,40^2)."""
 import json
@@ -32,6 +32,8 @@ def main():
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
     imgs, labels = samples(n=N // 2)
     hard = len(sys.argv) > 3 and sys.argv[3] == "hard"
+    lbp = len(sys.argv) > 4 and sys.argv[4] == "LBP"  # the same stage over the 8 464 categorical LBP variables
+    ftype = ev.LBP if lbp else ev.HAAR
     if hard:
         rng = np.random.default_rng(7)
         t1 = rng.integers(0, 256, (24, 24)).astype(np.float64)
@@ -43,14 +45,14 @@ def main():
     resp = y.astype(np.float32)
     # process start-up (HIP context, code-object load) is not stage work: a throw-away evaluator takes it first
     t0 = time.perf_counter()
-    w0 = cc.CvFeatureEvaluator.create(ev.HAAR)
-    w0.init(cc.CvFeatureParams(ev.HAAR, ev.BASIC), 64, (24, 24))
+    w0 = cc.CvFeatureEvaluator.create(ftype)
+    w0.init(cc.CvFeatureParams(ftype, ev.BASIC), 64, (24, 24))
     w0.setImages(imgs[:64], labels[:64])
     del w0
     t_startup = time.perf_counter() - t0
     t0 = time.perf_counter()
-    e = cc.CvFeatureEvaluator.create(ev.HAAR)
-    e.init(cc.CvFeatureParams(ev.HAAR, ev.BASIC), N, (24, 24))
+    e = cc.CvFeatureEvaluator.create(ftype)
+    e.init(cc.CvFeatureParams(ftype, ev.BASIC), N, (24, 24))
     e.setImages(imgs, labels)
     t_set = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -77,7 +79,11 @@ def main():
         v = e.calc_batch(sp["var_idx"], sp["var_idx"] + 1)[0]
         t_row += time.perf_counter() - t0
         t0 = time.perf_counter()
-        left = v <= sp["ord_c"]
+        if lbp:  # CV_DTREE_CAT_DIR: a sample goes left when its category's bit is set in the split's subset
+            code = v.astype(np.int64)
+            left = ((np.ascontiguousarray(sp["subset"], dtype=np.int32).view(np.uint32)[code >> 5] >> (code & 31).astype(np.uint32)) & 1).astype(bool)
+        else:
+            left = v <= sp["ord_c"]
         f = np.empty(N)
         for side in (left, ~left):
             sw = seq_sum(w[side])
@@ -88,7 +94,7 @@ def main():
         t_host += time.perf_counter() - t0
         chosen.append(int(sp["var_idx"]))
         errs.append(float(np.mean(np.sign(F) != y)))
-    out = {"data": "hard" if hard else "easy (SURVEY config 5)", "workload": f"Gentle AdaBoost, {rounds} stumps, Haar BASIC 24x24 ({e.getNumFeatures()} variables) x {N} samples (seed 7)",
+    out = {"data": "hard" if hard else "easy (SURVEY config 5)", "workload": f"Gentle AdaBoost, {rounds} stumps, {'LBP' if lbp else 'Haar BASIC'} 24x24 ({e.getNumFeatures()} variables) x {N} samples (seed 7)",
            "process_startup_s": round(t_startup, 3), "set_images_s": round(t_set, 3), "presort_s": round(t_presort, 3),
            "per_weak_learner_ms": {"split_search_wall": round(t_split / rounds * 1e3, 3), "split_search_kernel": round(float(np.mean(kernel_ms)), 3),
                                    "feature_row": round(t_row / rounds * 1e3, 3), "host_bookkeeping_numpy": round(t_host / rounds * 1e3, 3)},
