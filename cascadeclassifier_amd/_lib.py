@@ -148,6 +148,7 @@ SIGNATURES = {
     "cc_negminer_destroy": (None, [_vp]),
     "cc_negminer_plan": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(_i), C.POINTER(C.c_int64)]),
     "cc_negminer_run": (_i, [_vp, _vp, _i, _i, _sz, _i, _i, _vp, C.c_int64, C.POINTER(C.c_int64), _vp, _vp, _i, C.POINTER(_i)]),
+    "cc_negminer_run_batch": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _i, _vp, C.c_int64, C.POINTER(C.c_int64), _vp, _vp, _i, C.POINTER(_i)]),
 }
 
 _lib = None

@@ -548,7 +548,8 @@ struct MineArgs {
   const int* tree_root;
   const int* tree_leaf0;
   const float* leaves;
-  uint8_t* pass;
+  uint8_t* pass;   // [image][n_windows]
+  int nchan;       // channels per image in integ: image f starts at integ + f * nchan * chan_elems (blockIdx.y = image)
 };
 
 template <bool HAAR>
@@ -561,13 +562,14 @@ __global__ __launch_bounds__(256) void k_negmine_windows(MineArgs A) {
   const int k = (int)(i - L.win_first);
   const int gy = k / L.nx, gx = k - gy * L.nx;
   const int x = A.ox + gx * A.sx, y = A.oy + gy * A.sy;
-  const int32_t* sum = A.integ + L.int_ofs;
-  const int32_t* til = A.integ + 2 * A.chan_elems + L.int_ofs;
+  const int32_t* integ = A.integ + (size_t)blockIdx.y * A.nchan * A.chan_elems;
+  const int32_t* sum = integ + L.int_ofs;
+  const int32_t* til = integ + 2 * A.chan_elems + L.int_ofs;
   const int P = L.pitchI;
   const size_t base = (size_t)y * P + x;
   float nf = 1.f;
   if (HAAR) {  // calcNormFactor, features.cpp:13-25 (the 4-corner difference of the wrapped squared sums is exact)
-    const unsigned* sq = reinterpret_cast<const unsigned*>(A.integ + A.chan_elems + L.int_ofs);
+    const unsigned* sq = reinterpret_cast<const unsigned*>(integ + A.chan_elems + L.int_ofs);
     const int nw = A.W0 - 2, nh = A.H0 - 2;
     const size_t q = base + P + 1;
     const int vs = sum[q] - sum[q + nw] - sum[q + (size_t)nh * P] + sum[q + (size_t)nh * P + nw];
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(256) void k_negmine_windows(MineArgs A) {
     }
     if (acc < (double)A.stage_thr[st]) pass = 0;
   }
-  A.pass[i] = pass;
+  A.pass[(size_t)blockIdx.y * A.n_windows + i] = pass;
 }
 
 // Same stream, one WAVEFRONT per window: the 64 lanes take the stumps of a stage (stump t = first + lane, + 64, ...), their
@@ -648,13 +650,14 @@ __global__ __launch_bounds__(256) void k_negmine_wave(MineArgs A) {
   const int k = (int)(i - L.win_first);
   const int gy = k / L.nx, gx = k - gy * L.nx;
   const int x = A.ox + gx * A.sx, y = A.oy + gy * A.sy;
-  const int32_t* sum = A.integ + L.int_ofs;
-  const int32_t* til = A.integ + 2 * A.chan_elems + L.int_ofs;
+  const int32_t* integ = A.integ + (size_t)blockIdx.y * A.nchan * A.chan_elems;
+  const int32_t* sum = integ + L.int_ofs;
+  const int32_t* til = integ + 2 * A.chan_elems + L.int_ofs;
   const int P = L.pitchI;
   const size_t base = (size_t)y * P + x;
   float nf = 1.f;
   if (HAAR) {
-    const unsigned* sq = reinterpret_cast<const unsigned*>(A.integ + A.chan_elems + L.int_ofs);
+    const unsigned* sq = reinterpret_cast<const unsigned*>(integ + A.chan_elems + L.int_ofs);
     const int nw = A.W0 - 2, nh = A.H0 - 2;
     const size_t q = base + P + 1;
     const int vs = sum[q] - sum[q + nw] - sum[q + (size_t)nh * P] + sum[q + (size_t)nh * P + nw];
@@ -714,14 +717,17 @@ __global__ __launch_bounds__(256) void k_negmine_wave(MineArgs A) {
       break;
     }
   }
-  if (lane == 0) A.pass[i] = pass;
+  if (lane == 0) A.pass[(size_t)blockIdx.y * A.n_windows + i] = pass;
 }
 
 // copies the pixels of selected stream windows out of the ladder: one block per window
-__global__ __launch_bounds__(64) void k_negmine_gather(const uint8_t* __restrict__ pyr, const MineLevel* __restrict__ levels, int n_levels,
+__global__ __launch_bounds__(64) void k_negmine_gather(const uint8_t* __restrict__ pyr, size_t pyr_image_bytes, long long n_windows,
+                                                       const MineLevel* __restrict__ levels, int n_levels,
                                                        const long long* __restrict__ keep, int W0, int H0, int ox, int oy, int sx, int sy,
                                                        uint8_t* __restrict__ out) {
-  const long long i = keep[blockIdx.x];
+  const long long gi = keep[blockIdx.x];  // image * n_windows + stream index
+  const long long img = gi / n_windows, i = gi - img * n_windows;
+  pyr += (size_t)img * pyr_image_bytes;
   int l = 0;
   while (l + 1 < n_levels && levels[l + 1].win_first <= i) l++;
   const MineLevel L = levels[l];
@@ -1014,8 +1020,20 @@ struct cc_negminer {
   DevBuf<int> d_resize_first, d_band_first, d_col_first, d_diag_first, d_tcol_first, d_xofs, d_yofs;
   DevBuf<uint16_t> d_xw1, d_yw1;
   DevBuf<long long> d_keep;
+  // The tables above depend on (image size, offset) only: consecutive images of a background set share them, so they are
+  // built and uploaded when that key changes, not per call.
+  struct Plan {
+    int width = -1, height = -1, ox = -1, oy = -1;
+    int nl = 0, n_resize = 0, n_bands = 0, n_cols = 0, n_diag = 0, n_tcol = 0;
+    long long pyr_bytes = 0, chan_elems = 0, h_elems = 0, wins = 0;
+  } plan;
+  uint8_t* h_src = nullptr;   // pinned: the images of a call, tight rows of align4(width)
+  uint8_t* h_pass = nullptr;  // pinned: pass flags on their way back
+  size_t h_src_bytes = 0, h_pass_bytes = 0;
   ~cc_negminer() {
     if (stream) (void)hipStreamDestroy(stream);
+    if (h_src) (void)hipHostFree(h_src);
+    if (h_pass) (void)hipHostFree(h_pass);
   }
 };
 
@@ -4245,14 +4263,11 @@ cc_status cc_negminer_plan(const cc_negminer* m, int width, int height, int ox, 
   return CC_OK;
 }
 
-cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int height, size_t row_stride, int ox, int oy, uint8_t* pass,
-                          int64_t cap, int64_t* n_windows, uint8_t* pixels, int64_t* keep_index, int max_keep, int* n_keep) {
-  cc_status st = mine_check(m, width, height, ox, oy, "cc_negminer_run");
-  if (st != CC_OK) return st;
-  if (!gray || !pass || !n_windows || row_stride < (size_t)width) return set_error(CC_ERR_INVALID_ARG, "cc_negminer_run: bad argument");
-  if (pixels && (!keep_index || !n_keep || max_keep < 0)) return set_error(CC_ERR_INVALID_ARG, "cc_negminer_run: bad keep buffers");
-  st = ensure_device(m->device);
-  if (st != CC_OK) return st;
+// Tables of one (image size, offset): ladder geometry, resize taps, kernel block maps. Cached in m->plan.
+static cc_status mine_plan(cc_negminer* m, int width, int height, int ox, int oy, const char* who) {
+  cc_negminer::Plan& P = m->plan;
+  if (P.width == width && P.height == height && P.ox == ox && P.oy == oy) return CC_OK;
+  P.width = -1;  // invalid until everything below has succeeded
   const Cascade& M = m->m;
   const int W0 = M.win_w, H0 = M.win_h;
   const bool haar = M.feature_type == CC_FEATURE_HAAR, tilt = haar && M.has_tilted;
@@ -4270,7 +4285,7 @@ cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int he
     std::memset(&S, 0, sizeof(S));
     S.w = g[i].w;
     S.h = g[i].h;
-    if (S.w < W0 + ox || S.h < H0 + oy) return set_error(CC_ERR_INVALID_ARG, "cc_negminer_run: ladder level %d (%dx%d) smaller than window + offset", i, S.w, S.h);
+    if (S.w < W0 + ox || S.h < H0 + oy) return set_error(CC_ERR_INVALID_ARG, "%s: ladder level %d (%dx%d) smaller than window + offset", who, i, S.w, S.h);
     S.pitch8 = align_up(S.w, 4);
     S.pitchI = align_up(S.w + 1, 4);
     S.img_ofs = img_ofs;
@@ -4305,11 +4320,7 @@ cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int he
     diag_first[i + 1] = diag_first[i] + (S.w + S.h - 1 + 255) / 256;
     tcol_first[i + 1] = tcol_first[i] + (S.w + 1 + 63) / 64;
   }
-  *n_windows = wins;
-  if (wins > cap) return set_error(CC_ERR_BUFFER_TOO_SMALL, "cc_negminer_run: %lld windows, capacity %lld", wins, (long long)cap);
   hipStream_t s = m->stream;
-  const int nchan = haar ? (tilt ? 3 : 2) : 1;
-  const size_t chan_elems = (size_t)int_ofs, spitch = (size_t)align_up(width, 4);
   CC_HIP(m->d_sd.upload(sd, s));
   CC_HIP(m->d_levels.upload(lv, s));
   CC_HIP(m->d_resize_first.upload(resize_first, s));
@@ -4321,26 +4332,118 @@ cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int he
   CC_HIP(m->d_yofs.upload(yofs, s));
   CC_HIP(m->d_xw1.upload(xw1, s));
   CC_HIP(m->d_yw1.upload(yw1, s));
-  CC_HIP(m->d_src.ensure(spitch * (size_t)height));
-  CC_HIP(m->d_pyr.ensure((size_t)((img_ofs + 15) & ~15LL)));
-  CC_HIP(m->d_integ.ensure(chan_elems * (size_t)nchan));
-  CC_HIP(m->d_hbuf.ensure(std::max<size_t>((size_t)h_ofs * (size_t)nchan, 4)));
-  CC_HIP(m->d_pass.ensure((size_t)std::max<long long>(wins, 1)));
-  CC_HIP(hipMemcpy2DAsync(m->d_src.p, spitch, gray, row_stride, (size_t)width, (size_t)height, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_resize, dim3(resize_first[nl], 1), dim3(256), 0, s, m->d_src.p, spitch, (size_t)0, width, height, m->d_pyr.p,
-                     (size_t)0, m->d_sd.p, nl, m->d_resize_first.p, m->d_xofs.p, m->d_xw1.p, m->d_yofs.p, m->d_yw1.p);
-  launch_integral(s, haar, m->d_pyr.p, 0, m->d_integ.p, chan_elems, nchan, m->d_hbuf.p, (size_t)h_ofs, m->d_sd.p, nl, m->d_band_first.p,
-                  band_first[nl], m->d_col_first.p, col_first[nl], 1);
+  if (tilt) CC_HIP(m->tilt.build(sd, s));
+  CC_HIP(hipStreamSynchronize(s));  // the uploads read host vectors that end here
+  P.nl = nl;
+  P.n_resize = resize_first[nl];
+  P.n_bands = band_first[nl];
+  P.n_cols = col_first[nl];
+  P.n_diag = diag_first[nl];
+  P.n_tcol = tcol_first[nl];
+  P.pyr_bytes = (img_ofs + 15) & ~15LL;
+  P.chan_elems = int_ofs;
+  P.h_elems = h_ofs;
+  P.wins = wins;
+  P.ox = ox;
+  P.oy = oy;
+  P.height = height;
+  P.width = width;
+  return CC_OK;
+}
+
+static cc_status pinned_ensure(uint8_t** p, size_t* have, size_t need) {
+  if (*have >= need) return CC_OK;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  *have = 0;
+  CC_HIP(hipHostMalloc(reinterpret_cast<void**>(p), need, hipHostMallocDefault));
+  *have = need;
+  return CC_OK;
+}
+
+// n_images images of one size, consumed with one offset: ONE copy to the device, one launch of every kernel over all of
+// them (the front-end kernels and the window kernels take the image as blockIdx.y, like the detector's frames), one copy back.
+static cc_status mine_images(cc_negminer* m, const uint8_t* const* images, int n_images, int width, int height, size_t row_stride, int ox,
+                             int oy, uint8_t* pass, int64_t cap, int64_t* n_windows, uint8_t* pixels, int64_t* keep_index, int max_keep,
+                             int* n_keep, const char* who) {
+  cc_status st = mine_check(m, width, height, ox, oy, who);
+  if (st != CC_OK) return st;
+  if (!images || n_images < 1 || !pass || !n_windows || row_stride < (size_t)width) return set_error(CC_ERR_INVALID_ARG, "%s: bad argument", who);
+  for (int k = 0; k < n_images; k++)
+    if (!images[k]) return set_error(CC_ERR_INVALID_ARG, "%s: image %d is null", who, k);
+  if (pixels && (!keep_index || !n_keep || max_keep < 0)) return set_error(CC_ERR_INVALID_ARG, "%s: bad keep buffers", who);
+  st = ensure_device(m->device);
+  if (st != CC_OK) return st;
+  st = mine_plan(m, width, height, ox, oy, who);
+  if (st != CC_OK) return st;
+  const cc_negminer::Plan& P = m->plan;
+  const Cascade& M = m->m;
+  const int W0 = M.win_w, H0 = M.win_h, nl = P.nl, K = n_images;
+  const bool haar = M.feature_type == CC_FEATURE_HAAR, tilt = haar && M.has_tilted;
+  const long long wins = P.wins;
+  *n_windows = wins;
+  if (wins * K > cap) return set_error(CC_ERR_BUFFER_TOO_SMALL, "%s: %lld windows (%d images), capacity %lld", who, wins * K, K, (long long)cap);
+  hipStream_t s = m->stream;
+  const int nchan = haar ? (tilt ? 3 : 2) : 1;
+  const size_t chan_elems = (size_t)P.chan_elems, spitch = (size_t)align_up(width, 4), src_bytes = spitch * (size_t)height;
+  CC_HIP(m->d_src.ensure(src_bytes * K));
+  CC_HIP(m->d_pyr.ensure((size_t)P.pyr_bytes * K));
+  CC_HIP(m->d_integ.ensure(chan_elems * (size_t)nchan * K));
+  CC_HIP(m->d_hbuf.ensure(std::max<size_t>((size_t)P.h_elems * (size_t)nchan * K, 4)));
+  CC_HIP(m->d_pass.ensure((size_t)std::max<long long>(wins * K, 1)));
+  st = pinned_ensure(&m->h_src, &m->h_src_bytes, src_bytes * K);
+  if (st != CC_OK) return st;
+  st = pinned_ensure(&m->h_pass, &m->h_pass_bytes, (size_t)std::max<long long>(wins * K, 1));
+  if (st != CC_OK) return st;
+  // Pageable rows -> pinned, tight rows, then asynchronous transfers: the images travel in pieces of >= 4 MB, a piece's copy to
+  // the device is issued as soon as it is staged, so the transfer of one piece runs under the staging of the next (a Full-HD
+  // background is 2 MB for 13 584 windows: the image's way to the device is most of what a call costs); large pieces are
+  // staged by up to 4 threads.
+  {
+    auto stage = [&](int ka, int kb) {
+      for (int k = ka; k < kb; k++) {
+        uint8_t* dst = m->h_src + (size_t)k * src_bytes;
+        if (row_stride == spitch)
+          std::memcpy(dst, images[k], (size_t)(height - 1) * spitch + (size_t)width);
+        else
+          for (int y = 0; y < height; y++) std::memcpy(dst + (size_t)y * spitch, images[k] + (size_t)y * row_stride, (size_t)width);
+      }
+    };
+    const int per_piece = (int)std::max<size_t>(1, ((size_t)4 << 20) / std::max<size_t>(src_bytes, 1));
+    for (int k0 = 0; k0 < K; k0 += per_piece) {
+      const int k1 = std::min(K, k0 + per_piece), n = k1 - k0;
+      const int nt = std::min({4, n, (int)std::max<size_t>(1, ((size_t)n * src_bytes) >> 21)});
+      if (nt <= 1) {
+        stage(k0, k1);
+      } else {
+        std::vector<std::future<void>> jobs;
+        try {
+          for (int t = 1; t < nt; t++) jobs.push_back(std::async(std::launch::async, stage, k0 + (int)((long long)n * t / nt), k0 + (int)((long long)n * (t + 1) / nt)));
+          stage(k0, k0 + n / nt);
+          for (auto& j : jobs) j.get();
+        } catch (const std::exception& e) {
+          for (auto& j : jobs)
+            if (j.valid()) j.wait();
+          return set_error(CC_ERR_HIP, "%s: staging the images: %s", who, e.what());
+        }
+      }
+      CC_HIP(hipMemcpyAsync(m->d_src.p + (size_t)k0 * src_bytes, m->h_src + (size_t)k0 * src_bytes, (size_t)n * src_bytes, hipMemcpyHostToDevice, s));
+    }
+  }
+  hipLaunchKernelGGL(k_resize, dim3(P.n_resize, K), dim3(256), 0, s, m->d_src.p, spitch, src_bytes, width, height, m->d_pyr.p,
+                     (size_t)P.pyr_bytes, m->d_sd.p, nl, m->d_resize_first.p, m->d_xofs.p, m->d_xw1.p, m->d_yofs.p, m->d_yw1.p);
+  launch_integral(s, haar, m->d_pyr.p, (size_t)P.pyr_bytes, m->d_integ.p, chan_elems, nchan, m->d_hbuf.p, (size_t)P.h_elems, m->d_sd.p, nl,
+                  m->d_band_first.p, P.n_bands, m->d_col_first.p, P.n_cols, K);
   if (tilt) {
-    CC_HIP(m->d_diag.ensure(chan_elems * 2));
-    CC_HIP(m->tilt.build(sd, s));
-    CC_HIP(m->d_tseg.ensure(std::max<size_t>(m->tilt.frame_elems, 1)));
-    launch_tilted(s, m->tilt, m->d_tseg.p, m->d_pyr.p, (size_t)0, m->d_diag.p, m->d_integ.p, chan_elems, nchan, 2, m->d_sd.p, nl,
-                  m->d_diag_first.p, diag_first[nl], m->d_tcol_first.p, tcol_first[nl], 1);
+    CC_HIP(m->d_diag.ensure(chan_elems * 2 * K));
+    CC_HIP(m->d_tseg.ensure(std::max<size_t>(m->tilt.frame_elems * K, 1)));
+    launch_tilted(s, m->tilt, m->d_tseg.p, m->d_pyr.p, (size_t)P.pyr_bytes, m->d_diag.p, m->d_integ.p, chan_elems, nchan, 2, m->d_sd.p, nl,
+                  m->d_diag_first.p, P.n_diag, m->d_tcol_first.p, P.n_tcol, K);
   }
   MineArgs A;
   A.integ = m->d_integ.p;
   A.chan_elems = chan_elems;
+  A.nchan = nchan;
   A.levels = m->d_levels.p;
   A.n_levels = nl;
   A.n_windows = wins;
@@ -4365,31 +4468,32 @@ cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int he
     if (wave_mode) {
       const unsigned nb = (unsigned)((wins + 3) / 4);
       if (haar)
-        hipLaunchKernelGGL(k_negmine_wave<true>, dim3(nb), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_negmine_wave<true>, dim3(nb, K), dim3(256), 0, s, A);
       else
-        hipLaunchKernelGGL(k_negmine_wave<false>, dim3(nb), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_negmine_wave<false>, dim3(nb, K), dim3(256), 0, s, A);
     } else {
       const unsigned nb = (unsigned)((wins + 255) / 256);
       if (haar)
-        hipLaunchKernelGGL(k_negmine_windows<true>, dim3(nb), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_negmine_windows<true>, dim3(nb, K), dim3(256), 0, s, A);
       else
-        hipLaunchKernelGGL(k_negmine_windows<false>, dim3(nb), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_negmine_windows<false>, dim3(nb, K), dim3(256), 0, s, A);
     }
   }
   CC_HIP(hipGetLastError());
-  if (wins > 0) CC_HIP(hipMemcpyAsync(pass, m->d_pass.p, (size_t)wins, hipMemcpyDeviceToHost, s));
+  if (wins > 0) CC_HIP(hipMemcpyAsync(m->h_pass, m->d_pass.p, (size_t)(wins * K), hipMemcpyDeviceToHost, s));
   CC_HIP(hipStreamSynchronize(s));
+  if (wins > 0) std::memcpy(pass, m->h_pass, (size_t)(wins * K));
   if (pixels) {
     std::vector<long long> keep;
-    for (long long i = 0; i < wins && (int)keep.size() < max_keep; i++)
+    for (long long i = 0; i < wins * K && (int)keep.size() < max_keep; i++)
       if (pass[i]) keep.push_back(i);
     *n_keep = (int)keep.size();
     if (!keep.empty()) {
       const size_t wsz = (size_t)W0 * H0;
       CC_HIP(m->d_keep.upload(keep, s));
       CC_HIP(m->d_pix.ensure(keep.size() * wsz));
-      hipLaunchKernelGGL(k_negmine_gather, dim3((unsigned)keep.size()), dim3(64), 0, s, m->d_pyr.p, m->d_levels.p, nl, m->d_keep.p, W0, H0, ox,
-                         oy, A.sx, A.sy, m->d_pix.p);
+      hipLaunchKernelGGL(k_negmine_gather, dim3((unsigned)keep.size()), dim3(64), 0, s, m->d_pyr.p, (size_t)P.pyr_bytes, wins, m->d_levels.p, nl,
+                         m->d_keep.p, W0, H0, ox, oy, A.sx, A.sy, m->d_pix.p);
       CC_HIP(hipGetLastError());
       CC_HIP(hipMemcpyAsync(pixels, m->d_pix.p, keep.size() * wsz, hipMemcpyDeviceToHost, s));
       CC_HIP(hipStreamSynchronize(s));
@@ -4397,6 +4501,21 @@ cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int he
     }
   }
   return CC_OK;
+}
+
+cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int height, size_t row_stride, int ox, int oy, uint8_t* pass,
+                          int64_t cap, int64_t* n_windows, uint8_t* pixels, int64_t* keep_index, int max_keep, int* n_keep) {
+  if (!m) return set_error(CC_ERR_INVALID_ARG, "cc_negminer_run: null miner");
+  return mine_images(m, &gray, 1, width, height, row_stride, ox, oy, pass, cap, n_windows, pixels, keep_index, max_keep, n_keep, "cc_negminer_run");
+}
+
+cc_status cc_negminer_run_batch(cc_negminer* m, const uint8_t* const* images, int n_images, int width, int height, size_t row_stride, int ox,
+                                int oy, uint8_t* pass, int64_t cap, int64_t* n_windows, uint8_t* pixels, int64_t* keep_index, int max_keep,
+                                int* n_keep) {
+  if (!m) return set_error(CC_ERR_INVALID_ARG, "cc_negminer_run_batch: null miner");
+  if (n_images > 256) return set_error(CC_ERR_INVALID_ARG, "cc_negminer_run_batch: at most 256 images per call (%d given)", n_images);
+  return mine_images(m, images, n_images, width, height, row_stride, ox, oy, pass, cap, n_windows, pixels, keep_index, max_keep, n_keep,
+                     "cc_negminer_run_batch");
 }
 
 }  // extern "C"

@@ -237,6 +237,24 @@ class NegativeMiner:
                                         max_keep, C.byref(nk)))
         return flags[:nw.value].copy(), pix[:nk.value].copy(), idx[:nk.value].copy()
 
+    def run_batch(self, imgs, ox=0, oy=0, max_keep=64):
+        """cc_negminer_run_batch: several images of one size, one offset (consecutive images of a background set). Returns
+        (flags [n_images][n_windows], kept pixels, kept indices as image * n_windows + stream index)."""
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in imgs]
+        h, w = imgs[0].shape
+        if any(im.shape != (h, w) for im in imgs):
+            raise ValueError("run_batch: images of one size only")
+        k = len(imgs)
+        per = self.plan(w, h, ox, oy)["n_windows"]
+        flags = np.zeros(max(per * k, 1), np.uint8)
+        pix = np.zeros((max(max_keep, 1), self.win[1], self.win[0]), np.uint8)
+        idx = np.zeros(max(max_keep, 1), np.int64)
+        ptrs = (C.c_void_p * k)(*[im.ctypes.data for im in imgs])
+        nw, nk = C.c_int64(0), C.c_int(0)
+        L.check(L.lib().cc_negminer_run_batch(self._m, ptrs, k, w, h, w, ox, oy, _vp(flags), per * k, C.byref(nw), _vp(pix), _vp(idx),
+                                              max_keep, C.byref(nk)))
+        return flags[:nw.value * k].reshape(k, nw.value).copy(), pix[:nk.value].copy(), idx[:nk.value].copy()
+
     def __del__(self):
         try:
             if self._m:

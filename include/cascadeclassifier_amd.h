@@ -389,6 +389,16 @@ CC_API cc_status cc_negminer_plan(const cc_negminer* m, int width, int height, i
 CC_API cc_status cc_negminer_run(cc_negminer* m, const uint8_t* gray, int width, int height, size_t row_stride, int ox, int oy,
                                  uint8_t* pass, int64_t cap, int64_t* n_windows, uint8_t* pixels, int64_t* keep_index,
                                  int max_keep, int* n_keep);
+/* The same for n_images (<= 256) images of ONE size consumed with ONE offset -- what NegReader::nextImg hands out between two
+ * wraps of its `round` counter over a background set of equal-sized images (imagestorage.cpp:57-88: the offset depends on
+ * `round` and the image size only). One copy to the device, one launch of every kernel over all images, one copy back: a call
+ * costs about what a single-image call costs. *n_windows = windows PER image; pass[k * *n_windows + i] for image k (cap >=
+ * n_images * *n_windows); the kept windows are the first max_keep passing ones in stream order, image 0 first, with
+ * keep_index[j] = k * *n_windows + i. A trainer that needs `need` more negatives walks pass[] in this order and stops where
+ * the per-window loop would have stopped (cascadeclassifier.cpp:329-357): results behind that point are simply not consumed. */
+CC_API cc_status cc_negminer_run_batch(cc_negminer* m, const uint8_t* const* images, int n_images, int width, int height,
+                                       size_t row_stride, int ox, int oy, uint8_t* pass, int64_t cap, int64_t* n_windows,
+                                       uint8_t* pixels, int64_t* keep_index, int max_keep, int* n_keep);
 
 /* ============================================================================================
  * 6. Best-split search of a boosted-tree node on the device.

@@ -75,6 +75,42 @@ def test_negative_mining_matches_reader_loop(tmp_path, haar_xml, lbp_xml, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["haar3", "lbp4", "haar_tilted", "haar_trees"])
+def test_batch_of_images_equals_one_call_per_image(tmp_path, haar_xml, lbp_xml, kind):
+    """cc_negminer_run_batch over several images of one size and offset = cc_negminer_run on each (and the oracle's reader
+    loop on the first and last): flags per image, and the kept windows are the first max_keep passing ones in stream order
+    across the images. Calls with other sizes / offsets in between exercise the plan cache."""
+    tmp = str(tmp_path)
+    calib = frame_natural(320, 240, 3)
+    wins = np.stack([calib[y:y + 24, x:x + 24] for y in range(0, 200, 9) for x in range(0, 280, 11)])
+    if kind == "haar3":
+        path = _truncated(haar_xml, 3, tmp)
+    elif kind == "lbp4":
+        path = _truncated(lbp_xml, 4, tmp)
+    else:
+        xml = {"haar_tilted": lambda: cf.tilted_stump_cascade(wins), "haar_trees": lambda: cf.haar_tree_cascade(wins, with_tilted=True)}[kind]()
+        path = os.path.join(tmp, kind + ".xml")
+        open(path, "w").write(xml)
+    o = orc.load_cascade_xml(path)
+    m = cc.NegativeMiner(cc.CascadeClassifier(path))
+    imgs = [frame_natural(300, 200, 70 + k) for k in range(5)] + [frame_uniform(300, 200, 90)]
+    for ox, oy, keep in ((0, 0, 37), (7, 3, 500), (0, 0, 0)):
+        m.run(frame_natural(123, 77, 5), 1, 1)  # another plan in between
+        single = [m.run(im, ox, oy, max_keep=10 ** 6) for im in imgs]
+        flags, pix, idx = m.run_batch(imgs, ox, oy, max_keep=keep)
+        assert flags.shape == (len(imgs), len(single[0][0]))
+        for k, (f1, p1, i1) in enumerate(single):
+            assert (flags[k] == f1).all(), f"image {k}: {(flags[k] != f1).sum()} windows differ"
+        want_idx = np.concatenate([i1 + k * flags.shape[1] for k, (f1, p1, i1) in enumerate(single)])[:keep]
+        want_pix = np.concatenate([p1 for f1, p1, i1 in single])[:keep]
+        assert (idx == want_idx).all() and (pix == want_pix).all()
+        for k in (0, len(imgs) - 1):
+            assert (flags[k] == orc.negmine_image(o, imgs[k], ox, oy, max_keep=1)[0]).all()
+    with pytest.raises(ValueError):
+        m.run_batch([imgs[0], frame_natural(301, 200, 1)])
+
+
+@pytest.mark.gpu
 def test_negative_miner_argument_checks(haar_xml):
     m = cc.NegativeMiner(cc.CascadeClassifier(haar_xml))
     with pytest.raises(cc.CascadeError):

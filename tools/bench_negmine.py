@@ -32,9 +32,25 @@ def main():
     for _ in range(reps):
         flags, pix, idx = m.run(img, max_keep=256)
     dt = (time.perf_counter() - t0) / reps
-    print(json.dumps({"workload": f"negative mining, 1920x1080 background, {K} trained stages, {plan['n_windows']} stream windows in "
-                                  f"{len(plan['levels'])} ladder levels", "wall_ms_per_image": round(dt * 1e3, 3),
-                      "mwindows_per_s": round(plan["n_windows"] / dt / 1e6, 2), "accepted": int(flags.sum())}))
+    out = {"workload": f"negative mining, 1920x1080 background, {K} trained stages, {plan['n_windows']} stream windows in "
+                       f"{len(plan['levels'])} ladder levels", "wall_ms_per_image": round(dt * 1e3, 3),
+           "mwindows_per_s": round(plan["n_windows"] / dt / 1e6, 2), "accepted": int(flags.sum())}
+    # cc_negminer_run_batch: B images of one size per call (consecutive images of a background set)
+    batches = {}
+    for (w, h) in ((1920, 1080), (640, 480)):
+        per = m.plan(w, h)["n_windows"]
+        for B in (1, 8, 32):
+            imgs = [frame_natural(w, h, 100 + k) for k in range(B)]
+            fb = m.run_batch(imgs, max_keep=256)[0]  # warm-up (sizes the workspace)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fb = m.run_batch(imgs, max_keep=256)[0]
+            dtb = (time.perf_counter() - t0) / reps
+            one = m.run(imgs[-1], max_keep=256)[0]
+            batches[f"{w}x{h} x {B}"] = {"wall_ms_per_call": round(dtb * 1e3, 3), "wall_ms_per_image": round(dtb / B * 1e3, 4),
+                                          "mwindows_per_s": round(per * B / dtb / 1e6, 1), "last_image_equals_single_call": bool((fb[-1] == one).all())}
+    out["run_batch"] = batches
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
