@@ -1030,7 +1030,11 @@ struct cc_negminer {
   uint8_t* h_src = nullptr;   // pinned: the images of a call, tight rows of align4(width)
   uint8_t* h_pass = nullptr;  // pinned: pass flags on their way back
   size_t h_src_bytes = 0, h_pass_bytes = 0;
+  hipStream_t copy_stream = nullptr;      // the images' way to the device, piece by piece, under the kernels of the piece before
+  std::vector<hipEvent_t> piece_landed;   // one per piece of a call (grown on demand)
   ~cc_negminer() {
+    for (hipEvent_t e : piece_landed) (void)hipEventDestroy(e);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
     if (h_src) (void)hipHostFree(h_src);
     if (h_pass) (void)hipHostFree(h_pass);
@@ -4197,6 +4201,7 @@ cc_status cc_negminer_create(const cc_cascade* c, int device, cc_negminer** out)
   m->m = c->m;
   m->device = device;
   CC_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  CC_HIP(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
   const Cascade& M = m->m;
   const bool haar = M.feature_type == CC_FEATURE_HAAR;
   std::vector<MineNode> nodes(M.node_feature.size());
@@ -4395,51 +4400,6 @@ static cc_status mine_images(cc_negminer* m, const uint8_t* const* images, int n
   if (st != CC_OK) return st;
   st = pinned_ensure(&m->h_pass, &m->h_pass_bytes, (size_t)std::max<long long>(wins * K, 1));
   if (st != CC_OK) return st;
-  // Pageable rows -> pinned, tight rows, then asynchronous transfers: the images travel in pieces of >= 4 MB, a piece's copy to
-  // the device is issued as soon as it is staged, so the transfer of one piece runs under the staging of the next (a Full-HD
-  // background is 2 MB for 13 584 windows: the image's way to the device is most of what a call costs); large pieces are
-  // staged by up to 4 threads.
-  {
-    auto stage = [&](int ka, int kb) {
-      for (int k = ka; k < kb; k++) {
-        uint8_t* dst = m->h_src + (size_t)k * src_bytes;
-        if (row_stride == spitch)
-          std::memcpy(dst, images[k], (size_t)(height - 1) * spitch + (size_t)width);
-        else
-          for (int y = 0; y < height; y++) std::memcpy(dst + (size_t)y * spitch, images[k] + (size_t)y * row_stride, (size_t)width);
-      }
-    };
-    const int per_piece = (int)std::max<size_t>(1, ((size_t)4 << 20) / std::max<size_t>(src_bytes, 1));
-    for (int k0 = 0; k0 < K; k0 += per_piece) {
-      const int k1 = std::min(K, k0 + per_piece), n = k1 - k0;
-      const int nt = std::min({4, n, (int)std::max<size_t>(1, ((size_t)n * src_bytes) >> 21)});
-      if (nt <= 1) {
-        stage(k0, k1);
-      } else {
-        std::vector<std::future<void>> jobs;
-        try {
-          for (int t = 1; t < nt; t++) jobs.push_back(std::async(std::launch::async, stage, k0 + (int)((long long)n * t / nt), k0 + (int)((long long)n * (t + 1) / nt)));
-          stage(k0, k0 + n / nt);
-          for (auto& j : jobs) j.get();
-        } catch (const std::exception& e) {
-          for (auto& j : jobs)
-            if (j.valid()) j.wait();
-          return set_error(CC_ERR_HIP, "%s: staging the images: %s", who, e.what());
-        }
-      }
-      CC_HIP(hipMemcpyAsync(m->d_src.p + (size_t)k0 * src_bytes, m->h_src + (size_t)k0 * src_bytes, (size_t)n * src_bytes, hipMemcpyHostToDevice, s));
-    }
-  }
-  hipLaunchKernelGGL(k_resize, dim3(P.n_resize, K), dim3(256), 0, s, m->d_src.p, spitch, src_bytes, width, height, m->d_pyr.p,
-                     (size_t)P.pyr_bytes, m->d_sd.p, nl, m->d_resize_first.p, m->d_xofs.p, m->d_xw1.p, m->d_yofs.p, m->d_yw1.p);
-  launch_integral(s, haar, m->d_pyr.p, (size_t)P.pyr_bytes, m->d_integ.p, chan_elems, nchan, m->d_hbuf.p, (size_t)P.h_elems, m->d_sd.p, nl,
-                  m->d_band_first.p, P.n_bands, m->d_col_first.p, P.n_cols, K);
-  if (tilt) {
-    CC_HIP(m->d_diag.ensure(chan_elems * 2 * K));
-    CC_HIP(m->d_tseg.ensure(std::max<size_t>(m->tilt.frame_elems * K, 1)));
-    launch_tilted(s, m->tilt, m->d_tseg.p, m->d_pyr.p, (size_t)P.pyr_bytes, m->d_diag.p, m->d_integ.p, chan_elems, nchan, 2, m->d_sd.p, nl,
-                  m->d_diag_first.p, P.n_diag, m->d_tcol_first.p, P.n_tcol, K);
-  }
   MineArgs A;
   A.integ = m->d_integ.p;
   A.chan_elems = chan_elems;
@@ -4462,21 +4422,88 @@ static cc_status mine_images(cc_negminer* m, const uint8_t* const* images, int n
   A.tree_leaf0 = m->d_tree_leaf0.p;
   A.leaves = m->d_leaves.p;
   A.pass = m->d_pass.p;
-  if (wins > 0) {
-    // one wavefront per window where the parallel stage sum is exact (stumps, order-independent sums); else one thread per window
-    const bool wave_mode = M.max_nodes_per_tree == 1 && stage_sums_order_independent(M) && !std::getenv("CCAMD_NEGMINE_THREAD_PER_WINDOW");
+  if (tilt) {
+    CC_HIP(m->d_diag.ensure(chan_elems * 2 * K));
+    CC_HIP(m->d_tseg.ensure(std::max<size_t>(m->tilt.frame_elems * K, 1)));
+  }
+  // one wavefront per window where the parallel stage sum is exact (stumps, order-independent sums); else one thread per window
+  const bool wave_mode = M.max_nodes_per_tree == 1 && stage_sums_order_independent(M) && !std::getenv("CCAMD_NEGMINE_THREAD_PER_WINDOW");
+  // Every kernel over the images [k0, k0 + n): the front-end kernels and the window kernels take the image as blockIdx.y.
+  auto launch_images = [&](int k0, int n) {
+    const uint8_t* src = m->d_src.p + (size_t)k0 * src_bytes;
+    uint8_t* pyr = m->d_pyr.p + (size_t)k0 * (size_t)P.pyr_bytes;
+    int32_t* integ = m->d_integ.p + (size_t)k0 * nchan * chan_elems;
+    hipLaunchKernelGGL(k_resize, dim3(P.n_resize, n), dim3(256), 0, s, src, spitch, src_bytes, width, height, pyr, (size_t)P.pyr_bytes,
+                       m->d_sd.p, nl, m->d_resize_first.p, m->d_xofs.p, m->d_xw1.p, m->d_yofs.p, m->d_yw1.p);
+    launch_integral(s, haar, pyr, (size_t)P.pyr_bytes, integ, chan_elems, nchan, m->d_hbuf.p + (size_t)k0 * nchan * (size_t)P.h_elems, (size_t)P.h_elems,
+                    m->d_sd.p, nl, m->d_band_first.p, P.n_bands, m->d_col_first.p, P.n_cols, n);
+    if (tilt)
+      launch_tilted(s, m->tilt, m->d_tseg.p + (size_t)k0 * m->tilt.frame_elems, pyr, (size_t)P.pyr_bytes, m->d_diag.p + (size_t)k0 * 2 * chan_elems, integ,
+                    chan_elems, nchan, 2, m->d_sd.p, nl, m->d_diag_first.p, P.n_diag, m->d_tcol_first.p, P.n_tcol, n);
+    if (wins == 0) return;
+    MineArgs B = A;
+    B.integ = integ;
+    B.pass = m->d_pass.p + (size_t)k0 * (size_t)wins;
     if (wave_mode) {
       const unsigned nb = (unsigned)((wins + 3) / 4);
       if (haar)
-        hipLaunchKernelGGL(k_negmine_wave<true>, dim3(nb, K), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_negmine_wave<true>, dim3(nb, n), dim3(256), 0, s, B);
       else
-        hipLaunchKernelGGL(k_negmine_wave<false>, dim3(nb, K), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_negmine_wave<false>, dim3(nb, n), dim3(256), 0, s, B);
     } else {
       const unsigned nb = (unsigned)((wins + 255) / 256);
       if (haar)
-        hipLaunchKernelGGL(k_negmine_windows<true>, dim3(nb, K), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_negmine_windows<true>, dim3(nb, n), dim3(256), 0, s, B);
       else
-        hipLaunchKernelGGL(k_negmine_windows<false>, dim3(nb, K), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_negmine_windows<false>, dim3(nb, n), dim3(256), 0, s, B);
+    }
+  };
+  // Pageable rows -> pinned, tight rows, then asynchronous transfers on the copy stream: the images travel in pieces of >= 8 MB;
+  // a piece's copy is issued as soon as it is staged (it runs under the staging of the next piece) and its kernels are queued
+  // behind it on the compute stream (they run under the next piece's copy). A Full-HD background is 2 MB for 13 584 windows:
+  // the image's way to the device is most of what a call costs. Large pieces are staged by up to 4 threads.
+  {
+    auto stage = [&](int ka, int kb) {
+      for (int k = ka; k < kb; k++) {
+        uint8_t* dst = m->h_src + (size_t)k * src_bytes;
+        if (row_stride == spitch)
+          std::memcpy(dst, images[k], (size_t)(height - 1) * spitch + (size_t)width);
+        else
+          for (int y = 0; y < height; y++) std::memcpy(dst + (size_t)y * spitch, images[k] + (size_t)y * row_stride, (size_t)width);
+      }
+    };
+    const int per_piece = (int)std::max<size_t>(1, ((size_t)8 << 20) / std::max<size_t>(src_bytes, 1));
+    const size_t n_pieces = ((size_t)K + per_piece - 1) / per_piece;
+    while (m->piece_landed.size() < n_pieces) {
+      hipEvent_t ev = nullptr;
+      CC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      m->piece_landed.push_back(ev);
+    }
+    size_t piece = 0;
+    for (int k0 = 0; k0 < K; k0 += per_piece, piece++) {
+      const int k1 = std::min(K, k0 + per_piece), n = k1 - k0;
+      const int nt = std::min({4, n, (int)std::max<size_t>(1, ((size_t)n * src_bytes) >> 21)});
+      if (nt <= 1) {
+        stage(k0, k1);
+      } else {
+        std::vector<std::future<void>> jobs;
+        try {
+          for (int t = 1; t < nt; t++) jobs.push_back(std::async(std::launch::async, stage, k0 + (int)((long long)n * t / nt), k0 + (int)((long long)n * (t + 1) / nt)));
+          stage(k0, k0 + n / nt);
+          for (auto& j : jobs) j.get();
+        } catch (const std::exception& e) {
+          for (auto& j : jobs)
+            if (j.valid()) j.wait();
+          (void)hipStreamSynchronize(m->copy_stream);
+          (void)hipStreamSynchronize(s);
+          return set_error(CC_ERR_HIP, "%s: staging the images: %s", who, e.what());
+        }
+      }
+      CC_HIP(hipMemcpyAsync(m->d_src.p + (size_t)k0 * src_bytes, m->h_src + (size_t)k0 * src_bytes, (size_t)n * src_bytes, hipMemcpyHostToDevice,
+                            m->copy_stream));
+      CC_HIP(hipEventRecord(m->piece_landed[piece], m->copy_stream));
+      CC_HIP(hipStreamWaitEvent(s, m->piece_landed[piece], 0));
+      launch_images(k0, n);
     }
   }
   CC_HIP(hipGetLastError());
