@@ -540,7 +540,9 @@ struct SplitCatArgs {
 };
 constexpr int SPLIT_CAT_UNROLL = 16;  // ranks per chunk: four 16-byte loads per lane
 constexpr int SPLIT_CAT_DEPTH = 6;    // chunks whose loads are in flight (one wavefront per SIMD: latency is hidden by distance, not by occupancy)
-constexpr int SPLIT_CAT_PAD_RANKS = (SPLIT_CAT_DEPTH + 2) * SPLIT_CAT_UNROLL;  // zeroed ranks behind the table: read-ahead without bounds checks
+// zeroed ranks behind the table: read-ahead without bounds checks. A trip that starts at rank r0 < n_pre consumes DEPTH chunks and
+// requests the DEPTH after them: ranks up to r0 + 2 * DEPTH * UNROLL - 1.
+constexpr int SPLIT_CAT_PAD_RANKS = (2 * SPLIT_CAT_DEPTH + 1) * SPLIT_CAT_UNROLL;
 // Table layout: [group][rank / 4][64 lanes][4 ranks] -- a lane reads four consecutive ranks of its variable with one 16-byte
 // load, a wavefront 1 KB per load instruction. Per-sample table: a sample outside the node is stored as +0.0 (8-byte form:
 // response * w, or w with the class in the sign bit) or {0, 0} (16-byte form), so it takes no test at all.
@@ -575,6 +577,7 @@ __global__ __launch_bounds__(256) void k_split_cat_sorted(SplitCatArgs A) {
   bool own = false;
   double a0 = 0, a1 = 0;
   constexpr int U = SPLIT_CAT_UNROLL, D = SPLIT_CAT_DEPTH;
+  static_assert(2 * D * U <= SPLIT_CAT_PAD_RANKS && U % 4 == 0, "table padding covers the read-ahead");
   uint4 buf[D][U / 4];
   auto load = [&](int r0, uint4(&x)[U / 4]) {
 #pragma unroll
