@@ -2506,7 +2506,8 @@ static cc_status run_device_pass(cc_detector* d, Plan* P, const uint8_t* dframes
     CC_HIP(hipStreamSynchronize(st));
     const int n_tiles_run = d->last_stamp_tiles;
     std::vector<unsigned long long> h((size_t)n_tiles_run * (size_t)nf * STAMP_SLOTS);
-    CC_HIP(hipMemcpy(h.data(), d->d_stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    CC_HIP(hipMemcpyAsync(h.data(), d->d_stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, d->stream));
+    CC_HIP(hipStreamSynchronize(d->stream));
     if (FILE* f = std::fopen(path, "wb")) {
       const int hdr[4] = {n_tiles_run, nf, STAMP_SLOTS, 0};
       std::fwrite(hdr, sizeof(int), 4, f);
@@ -2531,7 +2532,9 @@ static cc_status check_frame_args(const cc_detector* d, const uint8_t* frames, i
 }
 
 // The specialised kernel may use another tile height than the ahead-of-time kernels: its tile list is built on first use,
-// with a synchronous copy -- so before the pass is launched, and never from inside a hipGraph capture.
+// before the pass is launched and never from inside a hipGraph capture. The copy goes through the detector's own stream and
+// is waited for there: a copy on the legacy stream (plain hipMemcpy) is refused while ANY thread of the process captures a
+// graph, and fails that thread's capture with it (two detectors on two host threads, one of them capturing its single-image pass).
 static cc_status ensure_spec_tiles(cc_detector* d, Plan* P) {
   if (!d->spec_fn || d->m.max_nodes_per_tree > 1) return CC_OK;
   const int want[2][2] = {{d->spec_tile_y, d->spec_only_step}, {d->spec_fn1 ? d->spec_tile_y1 : 0, 1}};
@@ -2543,7 +2546,10 @@ static cc_status ensure_spec_tiles(cc_detector* d, Plan* P) {
     const std::vector<int4> tv = plan_tile_list(P->geom, w[0], w[1]);
     fresh->n = (int)tv.size();
     CC_HIP(fresh->d.ensure(std::max<size_t>(tv.size(), 1)));
-    if (!tv.empty()) CC_HIP(hipMemcpy(fresh->d.p, tv.data(), tv.size() * sizeof(int4), hipMemcpyHostToDevice));
+    if (!tv.empty()) {
+      CC_HIP(hipMemcpyAsync(fresh->d.p, tv.data(), tv.size() * sizeof(int4), hipMemcpyHostToDevice, d->stream));
+      CC_HIP(hipStreamSynchronize(d->stream));  // tv ends here
+    }
     tl = std::move(fresh);
   }
   return CC_OK;
@@ -4004,9 +4010,11 @@ cc_status cc_detect_debug_windows(cc_detector* d, const uint8_t* gray, int width
   if (P->windows > cap) return set_error(CC_ERR_BUFFER_TOO_SMALL, "cc_detect_debug_windows: %lld windows, capacity %lld", P->windows, (long long)cap);
   const size_t nw = (size_t)P->windows;
   if (nw) {
-    if (codes) CC_HIP(hipMemcpy(codes, d->d_dbg_codes.p, nw * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (sums) CC_HIP(hipMemcpy(sums, d->d_dbg_sums.p, nw * sizeof(double), hipMemcpyDeviceToHost));
-    if (visited) CC_HIP(hipMemcpy(visited, d->d_dbg_visited.p, nw, hipMemcpyDeviceToHost));
+    // through the detector's stream, not the legacy one: see ensure_spec_tiles
+    if (codes) CC_HIP(hipMemcpyAsync(codes, d->d_dbg_codes.p, nw * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+    if (sums) CC_HIP(hipMemcpyAsync(sums, d->d_dbg_sums.p, nw * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    if (visited) CC_HIP(hipMemcpyAsync(visited, d->d_dbg_visited.p, nw, hipMemcpyDeviceToHost, d->stream));
+    CC_HIP(hipStreamSynchronize(d->stream));
   }
   return CC_OK;
 }
