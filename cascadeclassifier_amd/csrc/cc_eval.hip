@@ -746,12 +746,17 @@ cc_status cc_debug_division_check(int device, uint64_t n_pairs, uint64_t seed, u
   CC_HIP(hipSetDevice(device));
   unsigned long long* d = nullptr;
   CC_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned long long)));
-  CC_HIP(hipMemset(d, 0, sizeof(unsigned long long)));
+  OwnStream own;  // not the legacy stream: see copy_sync
+  if (hipError_t es = own.create(); es != hipSuccess) {
+    (void)hipFree(d);
+    return set_error(CC_ERR_HIP, "cc_debug_division_check: %s", hipGetErrorString(es));
+  }
+  (void)hipMemsetAsync(d, 0, sizeof(unsigned long long), own.s);
   const int threads = 256, blocks = 4096;
   const int per_thread = (int)std::max<uint64_t>(1, std::min<uint64_t>((n_pairs + (uint64_t)threads * blocks - 1) / ((uint64_t)threads * blocks), 1u << 20));
-  hipLaunchKernelGGL(k_division_check, dim3(blocks), dim3(threads), 0, 0, (unsigned long long)seed, per_thread, d);
+  hipLaunchKernelGGL(k_division_check, dim3(blocks), dim3(threads), 0, own.s, (unsigned long long)seed, per_thread, d);
   unsigned long long h = 0;
-  const hipError_t e2 = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+  const hipError_t e2 = copy_sync(&h, d, sizeof(h), hipMemcpyDeviceToHost, own.s);
   (void)hipFree(d);
   if (e2 != hipSuccess) return set_error(CC_ERR_HIP, "cc_debug_division_check: %s", hipGetErrorString(e2));
   *mismatches = h;
@@ -813,14 +818,14 @@ cc_status cc_eval_create(int feature_type, int haar_mode, int win_w, int win_h, 
     std::vector<HaarFeatDev> dev(e->haar.size());
     for (size_t i = 0; i < dev.size(); i++) haar_to_dev(e->haar[i], win_w + 1, dev[i], e->S, e->use_tilted ? e->cols * e->S * 4 : 0);
     CC_HIP(e->d_haar.ensure(std::max<size_t>(dev.size(), 1)));
-    CC_HIP(hipMemcpy(e->d_haar.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(e->d_haar.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice, e->stream));
   } else {
     lbp_catalog(win_w, win_h, e->lbp);
     e->nfeat = (int)(e->lbp.size() / 4);
     std::vector<LbpFeatDev> dev((size_t)e->nfeat);
     for (int i = 0; i < e->nfeat; i++) lbp_to_dev(&e->lbp[(size_t)i * 4], win_w + 1, dev[i], e->S);
     CC_HIP(e->d_lbp.ensure(std::max<size_t>(dev.size(), 1)));
-    CC_HIP(hipMemcpy(e->d_lbp.p, dev.data(), dev.size() * sizeof(LbpFeatDev), hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(e->d_lbp.p, dev.data(), dev.size() * sizeof(LbpFeatDev), hipMemcpyHostToDevice, e->stream));
   }
   CC_HIP(hipStreamSynchronize(e->stream));
   *out = e.release();
@@ -1074,13 +1079,13 @@ cc_status cc_eval_calc_list(cc_evaluator* e, const int32_t* feature_idx, int n_f
     std::vector<HaarFeatDev> dev(e->haar.size());
     for (size_t i = 0; i < dev.size(); i++) haar_to_dev(e->haar[i], e->W + 1, dev[i]);
     CC_HIP(e->d_haar_plain.ensure(std::max<size_t>(dev.size(), 1)));
-    CC_HIP(hipMemcpy(e->d_haar_plain.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(e->d_haar_plain.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice, e->stream));
   }
   if (!haar && !e->d_lbp_plain.p) {
     std::vector<LbpFeatDev> dev((size_t)e->nfeat);
     for (int i = 0; i < e->nfeat; i++) lbp_to_dev(&e->lbp[(size_t)i * 4], e->W + 1, dev[i]);
     CC_HIP(e->d_lbp_plain.ensure(std::max<size_t>(dev.size(), 1)));
-    CC_HIP(hipMemcpy(e->d_lbp_plain.p, dev.data(), dev.size() * sizeof(LbpFeatDev), hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(e->d_lbp_plain.p, dev.data(), dev.size() * sizeof(LbpFeatDev), hipMemcpyHostToDevice, e->stream));
   }
   CC_HIP(e->d_idx.ensure((size_t)n_feats));
   CC_HIP(e->d_out.ensure((size_t)n_feats));
@@ -1169,21 +1174,23 @@ cc_status cc_haar_feature_calc(int device, const cc_haar_feature* feats, int n_f
   EBuf<int32_t> d_s, d_t;
   EBuf<float> d_o;
   const size_t nint = (size_t)n_rows * row_len, nout = (size_t)n_feats * n_rows;
+  OwnStream own;  // not the legacy stream: see copy_sync
+  CC_HIP(own.create());
   CC_HIP(d_f.ensure((size_t)n_feats));
-  CC_HIP(hipMemcpy(d_f.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice));
+  CC_HIP(copy_sync(d_f.p, dev.data(), dev.size() * sizeof(HaarFeatDev), hipMemcpyHostToDevice, own.s));
   if (sum) {
     CC_HIP(d_s.ensure(nint));
-    CC_HIP(hipMemcpy(d_s.p, sum, nint * 4, hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(d_s.p, sum, nint * 4, hipMemcpyHostToDevice, own.s));
   }
   if (tilted) {
     CC_HIP(d_t.ensure(nint));
-    CC_HIP(hipMemcpy(d_t.p, tilted, nint * 4, hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(d_t.p, tilted, nint * 4, hipMemcpyHostToDevice, own.s));
   }
   CC_HIP(d_o.ensure(nout));
-  hipLaunchKernelGGL(k_feature_calc_rows, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, nullptr, d_f.p, n_feats, d_s.p, d_t.p,
+  hipLaunchKernelGGL(k_feature_calc_rows, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, own.s, d_f.p, n_feats, d_s.p, d_t.p,
                      n_rows, row_len, d_o.p);
   CC_HIP(hipGetLastError());
-  CC_HIP(hipMemcpy(out, d_o.p, nout * 4, hipMemcpyDeviceToHost));
+  CC_HIP(copy_sync(out, d_o.p, nout * 4, hipMemcpyDeviceToHost, own.s));
   return CC_OK;
 }
 
@@ -1195,14 +1202,14 @@ cc_status cc_eval_get_sample(cc_evaluator* e, int idx, int32_t* sum, int32_t* ti
   std::lock_guard<std::mutex> lk(e->mu);
   st = flush_pending_images(e);  // the device's copy is what this call reports, also for a sample set a moment ago
   if (st != CC_OK) return st;
-  if (sum) CC_HIP(hipMemcpy(sum, e->d_sum.p + (size_t)idx * e->cols, (size_t)e->cols * 4, hipMemcpyDeviceToHost));
+  if (sum) CC_HIP(copy_sync(sum, e->d_sum.p + (size_t)idx * e->cols, (size_t)e->cols * 4, hipMemcpyDeviceToHost, e->stream));
   if (tilted) {
     if (!e->use_tilted) return set_error(CC_ERR_INVALID_ARG, "cc_eval_get_sample: evaluator keeps no tilted integrals (mode != ALL)");
-    CC_HIP(hipMemcpy(tilted, e->d_tilted.p + (size_t)idx * e->cols, (size_t)e->cols * 4, hipMemcpyDeviceToHost));
+    CC_HIP(copy_sync(tilted, e->d_tilted.p + (size_t)idx * e->cols, (size_t)e->cols * 4, hipMemcpyDeviceToHost, e->stream));
   }
   if (normfactor) {
     if (e->type != CC_FEATURE_HAAR) return set_error(CC_ERR_INVALID_ARG, "cc_eval_get_sample: LBP evaluator has no norm factor");
-    CC_HIP(hipMemcpy(normfactor, e->d_nf.p + idx, 4, hipMemcpyDeviceToHost));
+    CC_HIP(copy_sync(normfactor, e->d_nf.p + idx, 4, hipMemcpyDeviceToHost, e->stream));
   }
   return CC_OK;
 }
@@ -1245,40 +1252,40 @@ cc_status cc_eval_predict_cascade(cc_evaluator* e, const cc_cascade* c, const in
       haar_to_dev(f, e->W + 1, dev[i]);
     }
     CC_HIP(dh.ensure(ns));
-    CC_HIP(hipMemcpy(dh.p, dev.data(), ns * sizeof(HaarFeatDev), hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(dh.p, dev.data(), ns * sizeof(HaarFeatDev), hipMemcpyHostToDevice, e->stream));
   } else {
     std::vector<LbpFeatDev> dev(ns);
     for (size_t i = 0; i < ns; i++) lbp_to_dev(&m.lbp_rects[(size_t)rec_feature[i] * 4], e->W + 1, dev[i]);
     CC_HIP(dl.ensure(ns));
-    CC_HIP(hipMemcpy(dl.p, dev.data(), ns * sizeof(LbpFeatDev), hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(dl.p, dev.data(), ns * sizeof(LbpFeatDev), hipMemcpyHostToDevice, e->stream));
     CC_HIP(d_sub.ensure(ns * 8));
-    CC_HIP(hipMemcpy(d_sub.p, m.node_subset.data(), ns * 8 * 4, hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(d_sub.p, m.node_subset.data(), ns * 8 * 4, hipMemcpyHostToDevice, e->stream));
   }
   CC_HIP(d_ntrees.ensure(ntrees.size()));
-  CC_HIP(hipMemcpy(d_ntrees.p, ntrees.data(), ntrees.size() * 4, hipMemcpyHostToDevice));
+  CC_HIP(copy_sync(d_ntrees.p, ntrees.data(), ntrees.size() * 4, hipMemcpyHostToDevice, e->stream));
   CC_HIP(d_sthr.ensure(ntrees.size()));
-  CC_HIP(hipMemcpy(d_sthr.p, m.stage_threshold.data(), ntrees.size() * 4, hipMemcpyHostToDevice));
+  CC_HIP(copy_sync(d_sthr.p, m.stage_threshold.data(), ntrees.size() * 4, hipMemcpyHostToDevice, e->stream));
   CC_HIP(d_thr.ensure(ns));
-  CC_HIP(hipMemcpy(d_thr.p, rec_thr.data(), ns * 4, hipMemcpyHostToDevice));
+  CC_HIP(copy_sync(d_thr.p, rec_thr.data(), ns * 4, hipMemcpyHostToDevice, e->stream));
   EBuf<int> d_root, d_leaf0, d_nl, d_nr;
   EBuf<float> d_leaves;
   if (!trees) {
     CC_HIP(d_left.ensure(ns));
-    CC_HIP(hipMemcpy(d_left.p, m.stump_left.data(), ns * 4, hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(d_left.p, m.stump_left.data(), ns * 4, hipMemcpyHostToDevice, e->stream));
     CC_HIP(d_right.ensure(ns));
-    CC_HIP(hipMemcpy(d_right.p, m.stump_right.data(), ns * 4, hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(d_right.p, m.stump_right.data(), ns * 4, hipMemcpyHostToDevice, e->stream));
   } else {
     const size_t nt = m.tree_first_node.size();
     CC_HIP(d_root.ensure(nt));
-    CC_HIP(hipMemcpy(d_root.p, m.tree_first_node.data(), nt * 4, hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(d_root.p, m.tree_first_node.data(), nt * 4, hipMemcpyHostToDevice, e->stream));
     CC_HIP(d_leaf0.ensure(nt));
-    CC_HIP(hipMemcpy(d_leaf0.p, m.tree_first_leaf.data(), nt * 4, hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(d_leaf0.p, m.tree_first_leaf.data(), nt * 4, hipMemcpyHostToDevice, e->stream));
     CC_HIP(d_nl.ensure(ns));
-    CC_HIP(hipMemcpy(d_nl.p, m.node_left.data(), ns * 4, hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(d_nl.p, m.node_left.data(), ns * 4, hipMemcpyHostToDevice, e->stream));
     CC_HIP(d_nr.ensure(ns));
-    CC_HIP(hipMemcpy(d_nr.p, m.node_right.data(), ns * 4, hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(d_nr.p, m.node_right.data(), ns * 4, hipMemcpyHostToDevice, e->stream));
     CC_HIP(d_leaves.ensure(m.leaves.size()));
-    CC_HIP(hipMemcpy(d_leaves.p, m.leaves.data(), m.leaves.size() * 4, hipMemcpyHostToDevice));
+    CC_HIP(copy_sync(d_leaves.p, m.leaves.data(), m.leaves.size() * 4, hipMemcpyHostToDevice, e->stream));
   }
   CC_HIP(e->d_pred.ensure((size_t)n_samples));
   PredictArgs A;

@@ -47,6 +47,21 @@ struct EBuf {
 };
 
 
+// A blocking copy that stays off the legacy stream. Plain hipMemcpy / hipMemset are refused while ANY thread of the process
+// captures a hipGraph (the detector's single-image path captures one per scale plan) and fail that thread's capture with them;
+// stream-ordered copies on a non-blocking stream are not.
+inline hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+struct OwnStream {  // for entry points that have no evaluator to borrow a stream from
+  hipStream_t s = nullptr;
+  hipError_t create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+  ~OwnStream() {
+    if (s) (void)hipStreamDestroy(s);
+  }
+};
+
 struct PinnedBuf {
   void* p = nullptr;
   size_t bytes = 0;

@@ -102,3 +102,58 @@ def test_independent_detectors_on_concurrent_host_threads(haar_xml, lbp_xml):
     assert not errors, errors
     for got, want in zip(results, serial):
         assert all(a.shape == b.shape and (a == b).all() for a, b in zip(got, want))
+
+
+def test_trainer_side_calls_while_another_thread_captures_graphs(haar_xml):
+    """A detector's single-image path captures a hipGraph per scale plan. While ANY thread captures, the runtime refuses
+    copies on the legacy stream (plain hipMemcpy) in every other thread and fails the capture with them -- round 4 met that
+    between two detectors (the specialised modules' tile lists). One thread keeps capturing (new image sizes: a plan and a
+    capture each), the other goes through the evaluator's and the detector's entry points that copy: none may fail, and the
+    values stay the oracle's."""
+    import threading
+    from cascadeclassifier_amd import evaluator as ev
+    errors, stop = [], threading.Event()
+
+    def capturer():
+        try:
+            p = cc.CascadeClassifier(haar_xml)
+            p.specialize(3)
+            k = 0
+            while not stop.is_set() and k < 60:
+                img = frame_natural(200 + 8 * (k % 30), 150 + 4 * (k % 30), 500 + k)
+                a = p.detectMultiScale(img, 1.2, 2)  # sizes the buffers
+                b = p.detectMultiScale(img, 1.2, 2)  # captured
+                c = p.detectMultiScale(img, 1.2, 2)  # replayed
+                assert a.shape == b.shape == c.shape and (a == b).all() and (a == c).all()
+                k += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(("capturer", repr(e)))
+
+    def trainer():
+        try:
+            rng = np.random.default_rng(3)
+            imgs = rng.integers(0, 256, (40, 24, 24), dtype=np.uint8)
+            s, t, nf = orc.set_images(imgs, want_tilted=False, want_norm=True)
+            cat = orc.haar_catalog(24, 24, ev.BASIC)
+            want = orc.haar_eval_batch(cat, 100, 140, s, t, nf, 24, 24, None)
+            for it in range(12):
+                e = cc.CvFeatureEvaluator.create(ev.HAAR)
+                e.init(cc.CvFeatureParams(ev.HAAR, ev.BASIC), 40, (24, 24))
+                e.setImages(imgs, np.zeros(40, np.uint8))
+                got = e.calc_batch(100, 140)
+                assert (got == want).all()
+                assert e(100, 7) == want[0, 7]
+                p = cc.CascadeClassifier(haar_xml)
+                p.specialize(4)  # tile lists of the specialised modules: a copy per new plan
+                p.detect_batch(np.stack([frame_natural(300 + 4 * it, 200, 40 + it)] * 2), 1.2, 2)
+                p.debug_windows(frame_natural(120, 90 + it, 9), 1.2)
+        except Exception as e:  # noqa: BLE001
+            errors.append(("trainer", repr(e)))
+
+    a, b = threading.Thread(target=capturer), threading.Thread(target=trainer)
+    a.start()
+    b.start()
+    b.join()
+    stop.set()
+    a.join()
+    assert not errors, errors
