@@ -240,6 +240,88 @@ def measure_training_eval(cc, torch):
             "values_identical_to_cpu_oracle_rows": [f0, f1], "values_identical_to_cpu_oracle": bool((got.view(np.uint32) == want.view(np.uint32)).all())}
 
 
+def measure_split_search(cc, kind):
+    """SURVEY 8f-2 beside the headline (rank 0, N = 1): one node's best-split search over every variable of a 24x24 catalog
+    (Haar BASIC: 162 336 ordered variables; LBP: 8 464 categorical ones) x 20 000 samples, after one presort -- the call that
+    replaces CvDTree::find_best_split (o_cvdtree.cpp:313-357). Gentle AdaBoost's regression search; the winner is compared with
+    the CPU oracle's search over the 256 variables around it."""
+    import numpy as np
+    from cascadeclassifier_amd import evaluator as ev
+    from oracle import oracle as orc
+    rng = np.random.default_rng(7)
+    n = 10000
+    tmpl = rng.integers(0, 256, (24, 24)).astype(np.float64)
+    pos = np.clip(np.rint(tmpl + rng.normal(0, 40, (n, 24, 24))), 0, 255).astype(np.uint8)
+    neg = np.clip(np.rint(0.5 * tmpl + 0.5 * rng.integers(0, 256, (24, 24)) + rng.normal(0, 40, (n, 24, 24))), 0, 255).astype(np.uint8)
+    imgs, labels = np.concatenate([pos, neg]), np.concatenate([np.ones(n, np.uint8), np.zeros(n, np.uint8)])
+    N = len(imgs)
+    ftype = ev.HAAR if kind == "HAAR" else ev.LBP
+    e = cc.CvFeatureEvaluator.create(ftype)
+    e.init(cc.CvFeatureParams(ftype, ev.BASIC), N, (24, 24))
+    e.setImages(imgs, labels)
+    t0 = time.perf_counter()
+    e.presort()
+    presort_s = time.perf_counter() - t0
+    resp = (labels.astype(np.float32) * 2 - 1)
+    w = rng.random(N) + 0.05
+    w /= w.sum()
+    tot = float(np.cumsum(w)[-1])
+    W = np.concatenate([w, [tot, 0.0]])
+    nv = float(np.cumsum(resp * w)[-1] * (1.0 / tot))
+    e.find_best_split(W, responses=resp, node_value=nv)  # warm-up
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        got = e.find_best_split(W, responses=resp, node_value=nv)
+    wall = (time.perf_counter() - t0) / reps
+    F = e.getNumFeatures()
+    lo = max(0, min(got["var_idx"] - 128, F - 256))
+    s, t, nf = orc.set_images(imgs, want_tilted=False, want_norm=ftype == ev.HAAR)
+    if ftype == ev.HAAR:
+        vals = orc.haar_eval_batch(orc.haar_catalog(24, 24, ev.BASIC), lo, lo + 256, s, t, nf, 24, 24)
+    else:
+        vals = orc.lbp_eval_batch(orc.lbp_catalog(24, 24), lo, lo + 256, s, 24, 24)
+    want = orc.find_best_split(vals, W, categorical=ftype == ev.LBP, responses=resp, node_value=nv)
+    same = bool(bool(want["found"]) and int(want["var_idx"]) + lo == int(got["var_idx"]) and float(want["quality"]) == float(got["quality"]))
+    return {"workload": f"best-split search of one tree node (SURVEY 8f-2): {'Haar BASIC' if ftype == ev.HAAR else 'LBP'} 24x24, {F} variables x {N} samples, Gentle AdaBoost",
+            "value": round(wall * 1e3, 3), "unit": "ms per node (whole cc_eval_find_best_split call)", "kernel_ms": round(e.last_kernel_ms(), 3),
+            "presort_s_per_stage": round(presort_s, 3), "winner_identical_to_cpu_oracle_over_256_variables_around_it": same,
+            "values_identical_to_cpu_oracle": same}
+
+
+def measure_negative_mining(cc):
+    """SURVEY 8f-1 beside the headline (rank 0, N = 1): the reader's window stream of 32 background images per call
+    (cc_negminer_run_batch) through the first 10 stages of the headline cascade; image 0's flags are compared with the CPU
+    oracle's window-by-window loop."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    from cascadeclassifier_amd import evaluator as ev
+    from oracle import oracle as orc
+    from tests.util import frame_natural
+    xml = os.path.join(tempfile.mkdtemp(), "trunc.xml")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "truncate_cascade.py"),
+                           os.path.join(ROOT, "data", "haarcascade_frontalface_synthetic.xml"), "10", xml])
+    m = ev.NegativeMiner(cc.CascadeClassifier(xml))
+    res = {}
+    same = True
+    for (w, h) in ((640, 480), (1920, 1080)):
+        imgs = [frame_natural(w, h, 100 + k) for k in range(32)]
+        per = m.plan(w, h)["n_windows"]
+        flags = m.run_batch(imgs, max_keep=256)[0]  # warm-up
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            flags = m.run_batch(imgs, max_keep=256)[0]
+        dt = (time.perf_counter() - t0) / reps
+        if (w, h) == (640, 480):
+            same = bool((flags[0] == orc.negmine_image(orc.load_cascade_xml(xml), imgs[0], 0, 0, max_keep=1)[0]).all())
+        res[f"{w}x{h}"] = {"ms_per_image": round(dt / 32 * 1e3, 4), "mwindows_per_s": round(per * 32 / dt / 1e6, 1), "windows_per_image": per}
+    return {"workload": "batched negative mining (SURVEY 8f-1): 32 background images per call, 10 trained stages of the headline cascade",
+            "value": res["1920x1080"]["mwindows_per_s"], "unit": "M stream windows/s (1920x1080 backgrounds, wall time incl. the images' way to the device)",
+            "by_image_size": res, "values_identical_to_cpu_oracle": same}
+
+
 def spawn_ranks(n):
     """Starts n copies of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, 127.0.0.1 rendezvous on a free port) and
     waits for them. Returns the first non-zero exit status, or 0. If one rank dies the others are terminated, so a
@@ -709,8 +791,9 @@ def main():
             "rectangles_identical_to_gpu": ok if last is not None else None,
         }
     # The workloads SURVEY.md 8d lists beside the headline, each as a short run (rank 0, N = 1): the stock LBP cascade
-    # (BASELINE configs[2]), the headline cascade on i.i.d. uniform noise (distribution (i)), and the trainer's bulk feature
-    # evaluation (BASELINE configs[4]).
+    # (BASELINE configs[2]), the headline cascade on i.i.d. uniform noise (distribution (i)), the trainer's bulk feature
+    # evaluation (BASELINE configs[4]), and the two "next" rows of SURVEY 8f that have device kernels of their own: the node
+    # split search (both feature types) and batched negative mining.
     if extra_legs:
         del clf
         extras = []
@@ -724,6 +807,9 @@ def main():
                                                      make_frames(B, W, H, seed0=0, content="uniform"), args,
                                                      f"{W}x{H} headline cascade on i.i.d. uniform noise (SURVEY 8d distribution (i))"))
             extras.append(measure_training_eval(cc, torch))
+            extras.append(measure_split_search(cc, "HAAR"))
+            extras.append(measure_split_search(cc, "LBP"))
+            extras.append(measure_negative_mining(cc))
         except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
             extras.append({"error": str(e)})
         out["extra_workloads"] = extras
