@@ -6,7 +6,7 @@ uniform-noise frame; round 4 adds the kernel forms of that round (one module for
 the list queue from stage 1) and random LBP stump cascades of several window sizes (16-bit tiles of 20 / 16 / 8 window rows,
 list queue on / off). The shapes the generator treats differently all occur: stages shorter than the four parts of a stage,
 stages whose sums are exact (fixed-point votes, stumps re-ordered to share corners) and not (float accumulation in the
-cascade's order), rectangles whose sums exceed 16 bits. Usage on a GPU box: python tests/analysis/stress_specialised.py [n_cascades]
+cascade's order), rectangles whose sums exceed 16 bits. Usage on a GPU box: python tests/analysis/stress_specialised.py [n_cascades] [first_seed]
 Last run: profiles/r04_stress_specialised.txt."""
 import os
 import sys
@@ -24,11 +24,12 @@ from tests.util import frame_natural, frame_uniform  # noqa: E402
 
 def main():
     n_cascades = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     img, img2 = frame_natural(416, 300, 7), frame_uniform(200, 150, 8)
     cal = np.stack([img[y:y + 24, x:x + 24] for y in range(0, 270, 9) for x in range(0, 390, 11)])
     t0 = time.time()
     windows = 0
-    for seed in range(n_cascades):
+    for seed in range(seed0, seed0 + n_cascades):
         rng = np.random.default_rng(1000 + seed)
         sizes = tuple(int(v) for v in rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 47], size=int(rng.integers(2, 7))))
         xml = cf.tilted_stump_cascade(cal, seed=seed, stage_sizes=sizes, tilted=False, min_area=int(rng.choice([16, 100, 258])))
@@ -51,7 +52,7 @@ def main():
                 del os.environ[kk]
         print(f"cascade {seed}: stages {sizes}, {k} specialised: identical (32-bit, 16-bit and pair tiles; one module, other tile heights, list queue)", flush=True)
         os.remove(path)
-    for seed in range(n_cascades):
+    for seed in range(seed0, seed0 + n_cascades):
         rng = np.random.default_rng(5000 + seed)
         W, H = [(24, 24), (20, 20), (18, 30), (32, 16)][seed % 4]
         sizes = tuple(int(v) for v in rng.choice([1, 2, 3, 4, 6, 9, 14], size=int(rng.integers(2, 8))))
